@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native block-tridiagonal PCG.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[2], the one the north-star target is quoted on): stateSize n = 14,
+knotPoints N = 128, fp32, batch = 1024 independent problems PER GPU (configs[4] is this shape
+sharded over 8 GPUs: weak scaling, no data-path collective), synthetic Schur systems from
+gbd_pcg_amd.synth with the symmetric-stair preconditioner.
+
+A "step" = one batched PCG solve with a fixed iteration count (exit_tol = 0, max_iter = 25: the
+test |eta| < 0 never holds, /root/reference/include/pcg.cuh:195), lambda reset to 0 first, replayed
+from a hipGraph.  value = problem-iterations per second over the whole job.
+
+Printed JSON line (rank 0) also carries
+  roofline     : the dominant kernel (pcg_fused_kernel), algorithmic bytes / measured kernel time
+                 (HIP events on the launch stream) against the 8 TB/s HBM peak
+  spmv         : the standalone block-tridiagonal SpMV kernel, same accounting (the >= 70 % target)
+  cpu_baseline : the CPU oracle (oracle/pcg_oracle.c, a port -- the reference has no CPU path)
+                 timed on this host's cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip table)
+HBM_COPY_CEIL_GBPS = 6290.0  # measured float4-copy ceiling, same table
+
+N_STATE, N_KNOTS, BATCH_PER_GPU, MAX_ITER = 14, 128, 1024, 25
+
+
+def pcg_bytes_per_launch(n, N, batch, iters, s):
+    """Algorithmic HBM bytes of one fused solve: S and Pinv streamed once per iteration
+    (2 (3N-2) n^2 s) + the prologue's one pass over each + vectors
+    (gamma, lambda in; lambda, r, p out)."""
+    mat = (3 * N - 2) * n * n * s
+    return batch * ((2 * iters + 2) * mat + 5 * n * N * s)
+
+
+def spmv_bytes_per_launch(n, N, batch, s):
+    """((3N-2) n^2 + 2 n N) s per problem."""
+    return batch * ((3 * N - 2) * n * n + 2 * n * N) * s
+
+
+def cpu_baseline(n, N, iters, budget_s=12.0):
+    """Oracle (port) on the host cores, bounded sample of the same workload."""
+    import numpy as np
+    from gbd_pcg_amd import synth
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    probe = max(cores, 8)
+    d = synth.gen_numpy(n, N, seed=1234, batch=probe, dtype=np.float32)
+    t0 = time.perf_counter()
+    orc.pcg_batch(n, N, probe, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=iters, nthreads=cores)
+    t_probe = time.perf_counter() - t0
+    reps = max(1, int(budget_s / max(t_probe, 1e-3)))
+    reps = min(reps, 64)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.pcg_batch(n, N, probe, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=iters, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": probe * reps * iters / dt, "unit": "iter/s", "cores": cores, "kind": "port",
+            "sample": f"{probe} problems x {reps} repeats x {iters} iterations, n={n} N={N} fp32, "
+                      f"OpenMP over problems, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gbd_pcg_amd import binding, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n, N, B, iters = N_STATE, N_KNOTS, BATCH_PER_GPU, MAX_ITER
+    solver = binding.Solver(local_rank)
+    g = synth.gen_torch(n, N, B, "cuda", torch.float32, seed=1234 + 100003 * rank)
+    S, P, gamma = g["S"], g["Pinv"], g["gamma"]
+    lam = torch.zeros_like(gamma)
+    r, p = torch.empty_like(gamma), torch.empty_like(gamma)
+    it_out = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fl_out = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    graph = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, 0.0, iters, it_out, fl_out)
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        lam.zero_()
+        if ev:
+            ev[0].record(stream)
+        graph.launch(stream)
+        if ev:
+            ev[1].record(stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # RCCL over xGMI: throughput aggregation only
+        elapsed = float(t.item())
+    assert int(it_out.min()) == iters and int(it_out.max()) == iters
+    assert torch.isfinite(lam).all()
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    pcg_bytes = pcg_bytes_per_launch(n, N, B, iters, 4)
+    pcg_gbps = pcg_bytes / (kern_ms * 1e-3) / 1e9
+
+    # standalone SpMV over two distinct 308 MB matrices (S, Pinv) so the 256 MiB Infinity Cache
+    # cannot hold the stream between launches
+    x = torch.randn_like(gamma)
+    y = torch.empty_like(gamma)
+    for _ in range(4):
+        solver.spmv(n, N, B, S, x, y)
+        solver.spmv(n, N, B, P, x, y)
+    sp_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(sp_ev):
+        a.record(stream)
+        solver.spmv(n, N, B, S if k % 2 == 0 else P, x, y)
+        b.record(stream)
+    torch.cuda.synchronize()
+    sp_ms = sorted(a.elapsed_time(b) for a, b in sp_ev)[len(sp_ev) // 2]
+    sp_gbps = spmv_bytes_per_launch(n, N, B, 4) / (sp_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "PCG iterations/sec (problem-iterations, block-tridiag stateSize x knotPoints = 14 x 128)",
+            "value": world * B * iters * args.steps / elapsed,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: stateSize=14 knotPoints=128 fp32 batch=1024 per GPU, "
+                                   "25 fixed PCG iterations per step (exit_tol=0), symmetric-stair Pinv, "
+                                   "hipGraph replay",
+                       "stateSize": n, "knotPoints": N, "batch_per_gpu": B, "pcg_iters_per_step": iters,
+                       "path": "fused (one workgroup per problem)", "sharding": f"batch x{world}, no data-path collective"},
+            "solves_per_sec": world * B * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "kernel": "pcg_fused_kernel<float,14,2,4>", "achieved": pcg_gbps,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": pcg_gbps / HBM_PEAK_GBPS,
+                         "frac_of_copy_ceiling": pcg_gbps / HBM_COPY_CEIL_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": pcg_bytes, "kernel_ms": kern_ms},
+            "spmv": {"bound": "hbm", "kernel": "spmv_kernel<float,14,2,4>", "achieved": sp_gbps,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sp_gbps / HBM_PEAK_GBPS,
+                     "frac_of_copy_ceiling": sp_gbps / HBM_COPY_CEIL_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": spmv_bytes_per_launch(n, N, B, 4), "kernel_ms": sp_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, N, iters)
+        print(json.dumps(out), flush=True)
+
+    graph.close()
+    solver.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,525 @@
+// api.hip -- the C ABI of libgbdpcg.so (include/gbdpcg.h): handle, dispatch, graphs, host overloads.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/gbdpcg.h"
+#include "internal.hpp"
+
+using namespace gbdpcg;
+
+struct gbdpcg_context {
+    DeviceInfo dev;
+    gbdpcg_path forced = GBDPCG_PATH_AUTO;
+    hipError_t last_err = hipSuccess;
+    // status words for the blocking entry points (replace the per-call cudaMalloc of interface.cuh:105-108)
+    uint32_t *d_iters = nullptr;
+    uint8_t *d_exit = nullptr;
+    uint32_t *h_iters = nullptr;  // pinned
+    uint8_t *h_exit = nullptr;    // pinned
+    // split-path workspace, grown on demand outside capture
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+struct gbdpcg_graph {
+    gbdpcg_handle_t h = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace gbdpcg {
+
+template <typename T> int choose_vec(uint32_t n, const void *const *ptrs, int nptrs)
+{
+    const int cand[3] = {4, 2, 1};
+    for (int V : cand) {
+        if (V * sizeof(T) > 16 || n % V != 0 || n / V > 64) continue;
+        bool ok = true;
+        for (int i = 0; i < nptrs; ++i)
+            if (ptrs[i] && reinterpret_cast<uintptr_t>(ptrs[i]) % (V * sizeof(T)) != 0) ok = false;
+        if (ok) return V;
+    }
+    return 0;
+}
+template int choose_vec<float>(uint32_t, const void *const *, int);
+template int choose_vec<double>(uint32_t, const void *const *, int);
+
+}  // namespace gbdpcg
+
+namespace {
+
+gbdpcg_status fail(gbdpcg_handle_t h, hipError_t e)
+{
+    if (h) h->last_err = e;
+    return GBDPCG_ERR_HIP;
+}
+
+#define HIP_TRY(h, expr)                                \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) return fail((h), e__);   \
+    } while (0)
+
+bool shape_ok(uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (n == 0 || N == 0 || batch == 0) return false;
+    // index arithmetic inside the kernels is 32-bit within one problem
+    if ((uint64_t)3 * n * n * N >= (1ull << 31)) return false;
+    return true;
+}
+
+template <typename T> bool mappable(uint32_t n)
+{
+    const void *none[1] = {nullptr};
+    return choose_vec<T>(n, none, 1) != 0;
+}
+
+template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch)
+{
+    const bool fits = fused_fits<T>(h->dev, n, N);
+    if (h->forced == GBDPCG_PATH_FUSED) return fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT;
+    if (h->forced == GBDPCG_PATH_SPLIT) return GBDPCG_PATH_SPLIT;
+    if (!fits) return GBDPCG_PATH_SPLIT;
+    // A workgroup streams its problem's matrices at roughly one CU's share of bandwidth; with fewer
+    // problems than ~1/4 of the CUs and a matrix big enough that streaming dominates the launch
+    // boundaries of the split path, spreading one problem over many CUs wins.
+    const uint64_t mat_bytes = (uint64_t)6 * n * n * N * sizeof(T);
+    if (batch * 4 < (uint32_t)h->dev.num_cus && mat_bytes > (1u << 20)) return GBDPCG_PATH_SPLIT;
+    return GBDPCG_PATH_FUSED;
+}
+
+gbdpcg_status ensure_ws(gbdpcg_handle_t h, size_t bytes)
+{
+    if (bytes <= h->ws_bytes) return GBDPCG_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)cs;
+    if (h->ws) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipFree(h->ws));
+        h->ws = nullptr;
+        h->ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&h->ws, bytes);
+    if (e != hipSuccess) {
+        h->last_err = e;
+        return GBDPCG_ERR_ALLOC;
+    }
+    h->ws_bytes = bytes;
+    return GBDPCG_OK;
+}
+
+template <typename T>
+gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S, const T *d_Pinv,
+                         const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
+                         uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream)
+{
+    if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
+    PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED) {
+        HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+    } else {
+        const size_t need = split_workspace_bytes<T>(n, N, batch);
+        if (need > h->ws_bytes) {
+            // growing allocates and synchronises: not allowed while the stream is capturing
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return GBDPCG_ERR_ALLOC;
+            gbdpcg_status st = ensure_ws(h, need);
+            if (st != GBDPCG_OK) return st;
+        }
+        HIP_TRY(h, launch_pcg_split<T>(h->dev, a, h->ws, stream));
+    }
+    return GBDPCG_OK;
+}
+
+template <typename T>
+gbdpcg_status spmv_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_M, const T *d_x,
+                        T *d_y, hipStream_t stream)
+{
+    if (!h || !d_M || !d_x || !d_y || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    SpmvArgs<T> a{d_M, d_x, d_y, n, N, batch};
+    HIP_TRY(h, launch_spmv<T>(h->dev, a, stream));
+    return GBDPCG_OK;
+}
+
+template <typename T>
+gbdpcg_status solve_blocking_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, const T *d_S, const T *d_Pinv,
+                                  const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
+                                  uint32_t *h_iters, uint8_t *h_exit)
+{
+    if (!h) return GBDPCG_ERR_INVALID;
+    hipStream_t s = nullptr;  // the reference launches on the default stream (interface.cuh:132)
+    gbdpcg_status st =
+        solve_impl<T>(h, n, N, 1, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, h->d_iters, h->d_exit, s);
+    if (st != GBDPCG_OK) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->h_iters, h->d_iters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_exit, h->d_exit, sizeof(uint8_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));  // interface.cuh:136 synchronises through its blocking copy
+    if (h_iters) *h_iters = *h->h_iters;
+    if (h_exit) *h_exit = *h->h_exit;
+    return GBDPCG_OK;
+}
+
+template <typename T>
+gbdpcg_status solve_host_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, const T *h_S, const T *h_Pinv,
+                              const T *h_gamma, T *h_lambda, T tol, uint32_t max_iter, uint32_t *h_iters,
+                              uint8_t *h_exit)
+{
+    if (!h || !h_S || !h_gamma || !h_lambda || !shape_ok(n, N, 1)) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    const size_t mbytes = (size_t)3 * n * n * N * sizeof(T), vbytes = (size_t)n * N * sizeof(T);
+    // one allocation: S | Pinv | gamma | lambda (256-byte aligned pieces)
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t total = 2 * up(mbytes) + 2 * up(vbytes);
+    unsigned char *base = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), total);
+    if (e != hipSuccess) {
+        h->last_err = e;
+        return GBDPCG_ERR_ALLOC;
+    }
+    T *d_S = reinterpret_cast<T *>(base);
+    T *d_P = reinterpret_cast<T *>(base + up(mbytes));
+    T *d_g = reinterpret_cast<T *>(base + 2 * up(mbytes));
+    T *d_l = reinterpret_cast<T *>(base + 2 * up(mbytes) + up(vbytes));
+    gbdpcg_status st = GBDPCG_OK;
+    auto chk = [&](hipError_t err) {
+        if (err != hipSuccess && st == GBDPCG_OK) st = fail(h, err);
+    };
+    chk(hipMemcpy(d_S, h_S, mbytes, hipMemcpyHostToDevice));
+    if (h_Pinv) chk(hipMemcpy(d_P, h_Pinv, mbytes, hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_g, h_gamma, vbytes, hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_l, h_lambda, vbytes, hipMemcpyHostToDevice));
+    if (st == GBDPCG_OK)
+        st = solve_blocking_impl<T>(h, n, N, d_S, h_Pinv ? d_P : nullptr, d_g, d_l, nullptr, nullptr, tol, max_iter,
+                                    h_iters, h_exit);
+    if (st == GBDPCG_OK) chk(hipMemcpy(h_lambda, d_l, vbytes, hipMemcpyDeviceToHost));
+    (void)hipFree(base);
+    return st;
+}
+
+template <typename T>
+gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S,
+                                const T *d_Pinv, const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol,
+                                uint32_t max_iter, uint32_t *d_iters, uint8_t *d_exit, gbdpcg_graph_t *out)
+{
+    if (!h || !out) return GBDPCG_ERR_INVALID;
+    *out = nullptr;
+    if (!shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
+        gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
+        if (st != GBDPCG_OK) return st;
+    }
+    hipStream_t cs = nullptr;
+    HIP_TRY(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    gbdpcg_graph *g = new (std::nothrow) gbdpcg_graph;
+    if (!g) {
+        (void)hipStreamDestroy(cs);
+        return GBDPCG_ERR_ALLOC;
+    }
+    g->h = h;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    gbdpcg_status st = GBDPCG_OK;
+    if (e == hipSuccess) {
+        st = solve_impl<T>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit,
+                           cs);
+        hipError_t e2 = hipStreamEndCapture(cs, &g->graph);
+        if (st == GBDPCG_OK && e2 != hipSuccess) st = fail(h, e2);
+    } else {
+        st = fail(h, e);
+    }
+    if (st == GBDPCG_OK) {
+        e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) st = fail(h, e);
+    }
+    (void)hipStreamDestroy(cs);
+    if (st != GBDPCG_OK) {
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return st;
+    }
+    *out = g;
+    return GBDPCG_OK;
+}
+
+template <typename T>
+gbdpcg_status csr_to_bt_impl(uint32_t n, uint32_t N, const uint32_t *row_ptr, const uint32_t *col_ind,
+                             const T *val, T *h_M)
+{
+    if (!row_ptr || !col_ind || !val || !h_M || n == 0 || N == 0) return GBDPCG_ERR_INVALID;
+    const size_t total = (size_t)3 * n * n * N;
+    for (size_t i = 0; i < total; ++i) h_M[i] = T(0);
+    const uint32_t rows = n * N;
+    for (uint32_t row = 0; row < rows; ++row) {
+        const uint32_t k = row / n, r = row - k * n;
+        for (uint32_t q = row_ptr[row]; q < row_ptr[row + 1]; ++q) {
+            const uint32_t col = col_ind[q];
+            if (col >= rows) return GBDPCG_ERR_INVALID;
+            const uint32_t kc = col / n, c = col - kc * n;
+            if (kc + 1 < k || kc > k + 1) {
+                if (val[q] != T(0)) return GBDPCG_ERR_INVALID;  // outside the block-tridiagonal pattern
+                continue;
+            }
+            const uint32_t b = kc + 1 - k;  // 0: L, 1: D, 2: R
+            h_M[(size_t)k * 3 * n * n + (size_t)b * n * n + (size_t)c * n + r] += val[q];
+        }
+    }
+    return GBDPCG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
+{
+    if (!out) return GBDPCG_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return GBDPCG_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GBDPCG_ERR_NO_DEVICE;
+    // this library carries gfx950 code objects only
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GBDPCG_ERR_NO_DEVICE;
+    gbdpcg_context *h = new (std::nothrow) gbdpcg_context;
+    if (!h) return GBDPCG_ERR_ALLOC;
+    h->dev.device = device;
+    h->dev.num_cus = prop.multiProcessorCount;
+    h->dev.lds_per_cu = 160 * 1024;
+    h->dev.lds_per_wg_max = prop.sharedMemPerBlock > 0 && prop.sharedMemPerBlock < 160 * 1024
+                                ? (size_t)160 * 1024
+                                : (size_t)160 * 1024;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
+    if (e == hipSuccess) {
+        h->d_exit = reinterpret_cast<uint8_t *>(h->d_iters) + 128;
+        e = hipHostMalloc(reinterpret_cast<void **>(&h->h_iters), 256, hipHostMallocDefault);
+    }
+    if (e != hipSuccess) {
+        if (h->d_iters) (void)hipFree(h->d_iters);
+        delete h;
+        return GBDPCG_ERR_HIP;
+    }
+    h->h_exit = reinterpret_cast<uint8_t *>(h->h_iters) + 128;
+    *out = h;
+    return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
+{
+    if (!h) return GBDPCG_ERR_INVALID;
+    (void)hipSetDevice(h->dev.device);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->d_iters) (void)hipFree(h->d_iters);
+    if (h->h_iters) (void)hipHostFree(h->h_iters);
+    delete h;
+    return GBDPCG_OK;
+}
+
+const char *gbdpcg_status_string(gbdpcg_status s)
+{
+    switch (s) {
+    case GBDPCG_OK: return "ok";
+    case GBDPCG_ERR_INVALID: return "invalid argument";
+    case GBDPCG_ERR_HIP: return "HIP runtime error";
+    case GBDPCG_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case GBDPCG_ERR_UNSUPPORTED: return "unsupported shape";
+    case GBDPCG_ERR_TOO_LARGE: return "problem does not fit on the device";
+    case GBDPCG_ERR_ALLOC: return "allocation failed (or workspace growth requested during stream capture)";
+    case GBDPCG_ERR_NOT_IMPLEMENTED: return "not implemented";
+    }
+    return "unknown status";
+}
+
+int gbdpcg_last_hip_error(gbdpcg_handle_t h) { return h ? (int)h->last_err : (int)hipErrorInvalidValue; }
+const char *gbdpcg_last_hip_error_string(gbdpcg_handle_t h)
+{
+    return hipGetErrorString(h ? h->last_err : hipErrorInvalidValue);
+}
+
+gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path)
+{
+    if (!h || (int)path < 0 || (int)path > 2) return GBDPCG_ERR_INVALID;
+    h->forced = path;
+    return GBDPCG_OK;
+}
+
+gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (!h || !shape_ok(n, N, batch)) return GBDPCG_PATH_AUTO;
+    return elem_size == 8 ? pick_path<double>(h, n, N, batch) : pick_path<float>(h, n, N, batch);
+}
+
+size_t gbdpcg_pcg_shared_mem_size(uint32_t elem_size, uint32_t n, uint32_t N)
+{
+    const size_t nn = (size_t)n * n, mx = n > N ? n : N;
+    const size_t a = 6 * nn + 10 * (size_t)n + 2 * mx, b = 9 * nn;
+    return elem_size * (a > b ? a : b);
+}
+
+gbdpcg_status gbdpcg_check_occupancy(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (!h || (elem_size != 4 && elem_size != 8) || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    if (!(elem_size == 8 ? mappable<double>(n) : mappable<float>(n))) return GBDPCG_ERR_UNSUPPORTED;
+    // FUSED needs one workgroup's LDS; SPLIT needs its workspace in HBM and one (rpw=1) window in LDS.
+    const bool fits = elem_size == 8 ? fused_fits<double>(h->dev, n, N) : fused_fits<float>(h->dev, n, N);
+    if (fits) return GBDPCG_OK;
+    if ((size_t)3 * n * elem_size + 64 * elem_size > h->dev.lds_per_wg_max) return GBDPCG_ERR_TOO_LARGE;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+    const size_t need = gbdpcg_workspace_bytes(h, elem_size, n, N, batch);
+    return need <= free_b + h->ws_bytes ? GBDPCG_OK : GBDPCG_ERR_TOO_LARGE;
+}
+
+size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (!h || !shape_ok(n, N, batch)) return 0;
+    if (elem_size == 8) {
+        if (pick_path<double>(h, n, N, batch) == GBDPCG_PATH_FUSED) return 0;
+        return split_workspace_bytes<double>(n, N, batch);
+    }
+    if (pick_path<float>(h, n, N, batch) == GBDPCG_PATH_FUSED) return 0;
+    return split_workspace_bytes<float>(n, N, batch);
+}
+
+gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (!h || (elem_size != 4 && elem_size != 8) || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
+}
+
+gbdpcg_status gbdpcg_spmv_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const float *d_M,
+                              const float *d_x, float *d_y, void *stream)
+{
+    return spmv_impl<float>(h, n, N, batch, d_M, d_x, d_y, (hipStream_t)stream);
+}
+gbdpcg_status gbdpcg_spmv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const double *d_M,
+                              const double *d_x, double *d_y, void *stream)
+{
+    return spmv_impl<double>(h, n, N, batch, d_M, d_x, d_y, (hipStream_t)stream);
+}
+
+gbdpcg_status gbdpcg_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const float *d_S,
+                               const float *d_Pinv, const float *d_gamma, float *d_lambda, float *d_r, float *d_p,
+                               float tol, uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit,
+                               void *stream)
+{
+    return solve_impl<float>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters,
+                             d_max_iter_exit, (hipStream_t)stream);
+}
+gbdpcg_status gbdpcg_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const double *d_S,
+                               const double *d_Pinv, const double *d_gamma, double *d_lambda, double *d_r,
+                               double *d_p, double tol, uint32_t max_iter, uint32_t *d_iters,
+                               uint8_t *d_max_iter_exit, void *stream)
+{
+    return solve_impl<double>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters,
+                              d_max_iter_exit, (hipStream_t)stream);
+}
+
+gbdpcg_status gbdpcg_solve_blocking_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, const float *d_S,
+                                        const float *d_Pinv, const float *d_gamma, float *d_lambda, float *d_r,
+                                        float *d_p, float tol, uint32_t max_iter, uint32_t *h_iters,
+                                        uint8_t *h_max_iter_exit)
+{
+    return solve_blocking_impl<float>(h, n, N, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, h_iters,
+                                      h_max_iter_exit);
+}
+gbdpcg_status gbdpcg_solve_blocking_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, const double *d_S,
+                                        const double *d_Pinv, const double *d_gamma, double *d_lambda, double *d_r,
+                                        double *d_p, double tol, uint32_t max_iter, uint32_t *h_iters,
+                                        uint8_t *h_max_iter_exit)
+{
+    return solve_blocking_impl<double>(h, n, N, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, h_iters,
+                                       h_max_iter_exit);
+}
+
+gbdpcg_status gbdpcg_solve_host_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, const float *h_S,
+                                    const float *h_Pinv, const float *h_gamma, float *h_lambda, float tol,
+                                    uint32_t max_iter, uint32_t *h_iters, uint8_t *h_max_iter_exit)
+{
+    return solve_host_impl<float>(h, n, N, h_S, h_Pinv, h_gamma, h_lambda, tol, max_iter, h_iters, h_max_iter_exit);
+}
+gbdpcg_status gbdpcg_solve_host_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, const double *h_S,
+                                    const double *h_Pinv, const double *h_gamma, double *h_lambda, double tol,
+                                    uint32_t max_iter, uint32_t *h_iters, uint8_t *h_max_iter_exit)
+{
+    return solve_host_impl<double>(h, n, N, h_S, h_Pinv, h_gamma, h_lambda, tol, max_iter, h_iters,
+                                   h_max_iter_exit);
+}
+
+gbdpcg_status gbdpcg_graph_create_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                            const float *d_S, const float *d_Pinv, const float *d_gamma,
+                                            float *d_lambda, float *d_r, float *d_p, float tol, uint32_t max_iter,
+                                            uint32_t *d_iters, uint8_t *d_max_iter_exit, gbdpcg_graph_t *out)
+{
+    return graph_create_impl<float>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter,
+                                    d_iters, d_max_iter_exit, out);
+}
+gbdpcg_status gbdpcg_graph_create_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                            const double *d_S, const double *d_Pinv, const double *d_gamma,
+                                            double *d_lambda, double *d_r, double *d_p, double tol,
+                                            uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit,
+                                            gbdpcg_graph_t *out)
+{
+    return graph_create_impl<double>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter,
+                                     d_iters, d_max_iter_exit, out);
+}
+
+gbdpcg_status gbdpcg_graph_launch(gbdpcg_graph_t g, void *stream)
+{
+    if (!g || !g->exec) return GBDPCG_ERR_INVALID;
+    HIP_TRY(g->h, hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_graph_destroy(gbdpcg_graph_t g)
+{
+    if (!g) return GBDPCG_ERR_INVALID;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_form_pinv_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const float *d_S,
+                                   float *d_Pinv, gbdpcg_pinv_kind kind, void *stream)
+{
+    if (!h || !d_S || !d_Pinv || !shape_ok(n, N, batch) || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    HIP_TRY(h, launch_form_pinv<float>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, (hipStream_t)stream));
+    return GBDPCG_OK;
+}
+gbdpcg_status gbdpcg_form_pinv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const double *d_S,
+                                   double *d_Pinv, gbdpcg_pinv_kind kind, void *stream)
+{
+    if (!h || !d_S || !d_Pinv || !shape_ok(n, N, batch) || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    HIP_TRY(h, launch_form_pinv<double>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, (hipStream_t)stream));
+    return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_csr_to_bt_f32(uint32_t n, uint32_t N, const uint32_t *row_ptr, const uint32_t *col_ind,
+                                   const float *val, float *h_M)
+{
+    return csr_to_bt_impl<float>(n, N, row_ptr, col_ind, val, h_M);
+}
+gbdpcg_status gbdpcg_csr_to_bt_f64(uint32_t n, uint32_t N, const uint32_t *row_ptr, const uint32_t *col_ind,
+                                   const double *val, double *h_M)
+{
+    return csr_to_bt_impl<double>(n, N, row_ptr, col_ind, val, h_M);
+}
+
+const char *gbdpcg_version(void) { return "gbdpcg 0.1 gfx950"; }
+
+}  // extern "C"

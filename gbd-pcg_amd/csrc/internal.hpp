@@ -1,0 +1,62 @@
+// internal.hpp -- launcher declarations shared by the translation units of libgbdpcg.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace gbdpcg {
+
+// Device limits the launchers size against (filled once per handle).
+struct DeviceInfo {
+    int device = 0;
+    int num_cus = 256;
+    size_t lds_per_cu = 160 * 1024;   // MI355X: 160 KiB per CU, one workgroup may take all of it
+    size_t lds_per_wg_max = 160 * 1024;
+};
+
+template <typename T> struct SpmvArgs {
+    const T *M;
+    const T *x;
+    T *y;
+    uint32_t n, N, batch;
+};
+
+template <typename T> struct PcgArgs {
+    const T *S;
+    const T *Pinv;  // nullptr => identity
+    const T *gamma;
+    T *lambda;
+    T *r;  // nullable
+    T *p;  // nullable
+    T tol;
+    uint32_t max_iter;
+    uint32_t n, N, batch;
+    uint32_t *iters;         // [batch]
+    uint8_t *max_iter_exit;  // [batch], nullable
+};
+
+// Widest per-lane vector (in elements) usable for this block size and these base pointers:
+// V in {1,2,4}, n % V == 0, V*sizeof(T) <= 16, every pointer V*sizeof(T)-aligned, n/V <= 64.
+// Returns 0 when no mapping exists (n/V > 64 for every V).
+template <typename T> int choose_vec(uint32_t n, const void *const *ptrs, int nptrs);
+
+// ---- spmv.hip
+template <typename T> hipError_t launch_spmv(const DeviceInfo &dev, const SpmvArgs<T> &a, hipStream_t s);
+
+// ---- pcg_fused.hip : one workgroup per problem
+template <typename T> size_t fused_lds_bytes(uint32_t n, uint32_t N, uint32_t waves);
+template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_t N);
+template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s);
+
+// ---- pcg_split.hip : many workgroups per problem, two launches per iteration
+template <typename T> size_t split_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
+template <typename T>
+hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s);
+
+// ---- pinv.hip
+template <typename T>
+hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S,
+                            T *Pinv, int kind, hipStream_t s);
+
+}  // namespace gbdpcg

@@ -1,0 +1,259 @@
+// pcg_fused.hip -- batched PCG, one workgroup per problem, one launch per solve.
+//
+// Replaces the cooperative kernel pcg<T,n,N> (/root/reference/include/pcg.cuh:54-218).  The
+// reference keeps a knot's block-rows of S and Pinv in shared memory, gives every knot a block
+// and crosses the grid with 4 grid.sync() per iteration.  On MI355X a grid barrier costs
+// 4-26 us (MI355X_MICROARCH.md, barrier-xcd / barrier-cg), so this kernel turns the
+// decomposition around: the VECTORS (lambda, r, p, and the S p / Pinv r product) of one
+// problem live in one workgroup's LDS for the whole solve, S and Pinv are streamed from HBM
+// once per iteration by block_row_mv, and both inner products are reduced inside the
+// workgroup (wave butterfly -> WAVES partials in LDS -> same-order sum in every thread, which
+// keeps the convergence branch uniform like pcg.cuh:147,167,191 do).  No cross-CU traffic at
+// all; each problem exits on its own iteration count.  Algorithmic HBM bytes per
+// problem-iteration: 2 (3N-2) n^2 sizeof(T)  (SURVEY.md section 8d).
+//
+// Iteration restated from pcg.cuh:118-208 (see oracle/pcg_oracle_impl.inc for the sequential form).
+#include "bt_device.hpp"
+#include "internal.hpp"
+
+namespace gbdpcg {
+
+// LDS carve (elements of T), every array 16-byte aligned:
+//   xa  (N+2)n   padded SpMV input: lambda in the prologue, then p      (pads stay zero)
+//   xb  (N+2)n   padded SpMV input: r
+//   yc  N n      SpMV output: S lambda, then upsilon = S p, then r~ = Pinv r
+//   lam N n      lambda
+//   red 2*WAVES  per-wave partials of the two inner products
+template <typename T> struct FusedCarve {
+    uint32_t xa, xb, yc, lam, red, total;
+    __host__ __device__ FusedCarve(uint32_t n, uint32_t N, uint32_t waves) {
+        const uint32_t padded = align16<T>((N + 2) * n), plain = align16<T>(N * n);
+        xa = 0;
+        xb = xa + padded;
+        yc = xb + padded;
+        lam = yc + plain;
+        red = lam + plain;
+        total = red + align16<T>(2 * waves);
+    }
+};
+
+// y = M * X (X padded in LDS) for the block-rows of this wave; returns this LANE's partial of
+// dot(y, D) where D is a padded LDS vector (D + n is its first element).
+template <typename T, int NCT, int V, int WAVES>
+__device__ __forceinline__ T wg_spmv_dot(const T *__restrict__ M, const T *X, T *Y, const T *D,
+                                         const LaneMap<NCT, V> &m, uint32_t n, uint32_t N,
+                                         uint32_t lane, uint32_t wave)
+{
+    T part = T(0);
+    for (uint32_t k = wave; k < N; k += WAVES) {
+        T acc[V];
+        block_row_mv<T, NCT, V>(M + (size_t)k * 3 * n * n, X + k * n, m, lane, k == 0 ? n : 0u,
+                                k == N - 1 ? 2 * n : 3 * n, acc);
+        if (m.active && m.g == 0) {
+            const uint32_t row = k * n + m.rp * V;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                Y[row + v] = acc[v];
+                part = __builtin_fma(acc[v], D[n + row + v], part);
+            }
+        }
+    }
+    return part;
+}
+
+// Workgroup-wide sum of per-lane partials; every thread returns the same bits.
+// Ends with a barrier-protected read, so Y written before the call is visible after it.
+template <typename T, int WAVES>
+__device__ __forceinline__ T wg_sum(T part, T *red, uint32_t lane, uint32_t wave)
+{
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    T tot = red[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) tot += red[w];
+    return tot;
+}
+
+template <typename T, int NCT, int V, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+
+    constexpr uint32_t THREADS = WAVES * 64;
+    const uint32_t n = NCT ? (uint32_t)NCT : a.n;
+    const uint32_t N = a.N;
+    const uint32_t len = n * N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const FusedCarve<T> cv(n, N, WAVES);
+    T *xa = smem + cv.xa, *xb = smem + cv.xb, *yc = smem + cv.yc, *lam = smem + cv.lam;
+    T *red0 = smem + cv.red, *red1 = red0 + WAVES;
+    const LaneMap<NCT, V> m(n, lane);
+    const size_t mstride = (size_t)3 * n * n * N;
+
+    for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
+        const T *S = a.S + prob * mstride;
+        const T *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;
+        const T *gamma = a.gamma + (size_t)prob * len;
+        T *lambda = a.lambda + (size_t)prob * len;
+
+        // ---- prologue: r = gamma - S lambda ; r~ = Pinv r ; p = r~ ; eta = r.r~   (pcg.cuh:118-149)
+        for (uint32_t i = tid; i < n; i += THREADS) {
+            xa[i] = T(0); xa[n + len + i] = T(0);
+            xb[i] = T(0); xb[n + len + i] = T(0);
+        }
+        for (uint32_t i = tid; i < len; i += THREADS) {
+            const T l = lambda[i];
+            xa[n + i] = l;
+            lam[i] = l;
+            xb[n + i] = T(0);
+        }
+        __syncthreads();
+        (void)wg_spmv_dot<T, NCT, V, WAVES>(S, xa, yc, xb, m, n, N, lane, wave);
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += THREADS) xb[n + i] = gamma[i] - yc[i];
+        __syncthreads();
+
+        T eta;
+        {
+            T part = T(0);
+            if (P) {
+                part = wg_spmv_dot<T, NCT, V, WAVES>(P, xb, yc, xb, m, n, N, lane, wave);
+            } else {
+                for (uint32_t i = tid; i < len; i += THREADS) {
+                    const T rv = xb[n + i];
+                    yc[i] = rv;
+                    part = __builtin_fma(rv, rv, part);
+                }
+            }
+            eta = wg_sum<T, WAVES>(part, red1, lane, wave);
+        }
+        for (uint32_t i = tid; i < len; i += THREADS) xa[n + i] = yc[i];
+        __syncthreads();
+
+        // ---- main loop   (pcg.cuh:154-208)
+        uint32_t iter = 0;
+        bool max_iter_exit = true;
+        for (; iter < a.max_iter; ++iter) {
+            // upsilon = S p ; v = p.upsilon ; alpha = eta / v
+            T part = wg_spmv_dot<T, NCT, V, WAVES>(S, xa, yc, xa, m, n, N, lane, wave);
+            const T alpha = eta / wg_sum<T, WAVES>(part, red0, lane, wave);
+            // lambda += alpha p ; r -= alpha upsilon
+            for (uint32_t i = tid; i < len; i += THREADS) {
+                lam[i] = __builtin_fma(alpha, xa[n + i], lam[i]);
+                xb[n + i] = __builtin_fma(-alpha, yc[i], xb[n + i]);
+            }
+            __syncthreads();
+            // r~ = Pinv r ; eta_new = r.r~
+            if (P) {
+                part = wg_spmv_dot<T, NCT, V, WAVES>(P, xb, yc, xb, m, n, N, lane, wave);
+            } else {
+                part = T(0);
+                for (uint32_t i = tid; i < len; i += THREADS) {
+                    const T rv = xb[n + i];
+                    yc[i] = rv;
+                    part = __builtin_fma(rv, rv, part);
+                }
+            }
+            const T eta_new = wg_sum<T, WAVES>(part, red1, lane, wave);
+            if (fabs(eta_new) < a.tol) {  // pcg.cuh:195 (absolute test on r.Pinv r)
+                ++iter;
+                max_iter_exit = false;
+                break;
+            }
+            const T beta = eta_new / eta;
+            eta = eta_new;
+            // p = r~ + beta p
+            for (uint32_t i = tid; i < len; i += THREADS) xa[n + i] = __builtin_fma(beta, xa[n + i], yc[i]);
+            __syncthreads();
+        }
+
+        // ---- outputs   (pcg.cuh:212,215; d_r / d_p as left by :175,:205)
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += THREADS) {
+            lambda[i] = lam[i];
+            if (a.r) a.r[(size_t)prob * len + i] = xb[n + i];
+            if (a.p) a.p[(size_t)prob * len + i] = xa[n + i];
+        }
+        if (tid == 0) {
+            a.iters[prob] = iter;
+            if (a.max_iter_exit) a.max_iter_exit[prob] = max_iter_exit ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T> size_t fused_lds_bytes(uint32_t n, uint32_t N, uint32_t waves)
+{
+    return (size_t)FusedCarve<T>(n, N, waves).total * sizeof(T);
+}
+
+template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_t N)
+{
+    return fused_lds_bytes<T>(n, N, 16) <= dev.lds_per_wg_max;
+}
+
+template <typename T, int NCT, int V, int WAVES>
+static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
+{
+    const size_t lds = fused_lds_bytes<T>(a.n, a.N, WAVES);
+    if (lds > dev.lds_per_wg_max) return hipErrorInvalidValue;
+    auto kern = pcg_fused_kernel<T, NCT, V, WAVES>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // persistent over problems: at most as many workgroups as can be resident
+    uint32_t per_cu = (uint32_t)(dev.lds_per_cu / lds);
+    const uint32_t by_waves = 32 / WAVES;
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu == 0) per_cu = 1;
+    uint32_t grid = (uint32_t)dev.num_cus * per_cu;
+    if (grid > a.batch) grid = a.batch;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, int NCT, int V>
+static hipError_t launch_fused_v(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
+{
+    // few problems: give each the widest workgroup; many problems: 4-wave workgroups, several per CU
+    if (a.batch < (uint32_t)dev.num_cus) return launch_fused_w<T, NCT, V, 16>(dev, a, s);
+    return launch_fused_w<T, NCT, V, 4>(dev, a, s);
+}
+
+template <typename T, int NCT>
+static hipError_t launch_fused_n(const DeviceInfo &dev, const PcgArgs<T> &a, int V, hipStream_t s)
+{
+    if (V == 1) return launch_fused_v<T, NCT, 1>(dev, a, s);
+    if constexpr (NCT == 0 || NCT % 2 == 0) {
+        if (V == 2) return launch_fused_v<T, NCT, 2>(dev, a, s);
+    }
+    if constexpr (sizeof(T) == 4 && (NCT == 0 || NCT % 4 == 0)) {
+        if (V == 4) return launch_fused_v<T, NCT, 4>(dev, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
+{
+    const void *ptrs[] = {a.S, a.Pinv};
+    const int V = choose_vec<T>(a.n, ptrs, 2);
+    if (V == 0) return hipErrorInvalidValue;
+    switch (a.n) {
+    case 14: return launch_fused_n<T, 14>(dev, a, V, s);
+    case 36: return launch_fused_n<T, 36>(dev, a, V, s);
+    default: return launch_fused_n<T, 0>(dev, a, V, s);
+    }
+}
+
+template size_t fused_lds_bytes<float>(uint32_t, uint32_t, uint32_t);
+template size_t fused_lds_bytes<double>(uint32_t, uint32_t, uint32_t);
+template bool fused_fits<float>(const DeviceInfo &, uint32_t, uint32_t);
+template bool fused_fits<double>(const DeviceInfo &, uint32_t, uint32_t);
+template hipError_t launch_pcg_fused<float>(const DeviceInfo &, const PcgArgs<float> &, hipStream_t);
+template hipError_t launch_pcg_fused<double>(const DeviceInfo &, const PcgArgs<double> &, hipStream_t);
+
+}  // namespace gbdpcg

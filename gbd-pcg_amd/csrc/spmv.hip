@@ -1,0 +1,105 @@
+// spmv.hip -- batched block-tridiagonal SpMV  y = M x  (the HBM-roofline kernel).
+//
+// Replaces loadbdVec + bdmv (/root/reference/include/utils.cuh:9-85) as a standalone operator.
+// Work decomposition: a workgroup owns `rpw` consecutive block-rows of one problem; it stages the
+// (rpw+2)*n halo window of x in LDS once, then each of its wavefronts streams whole block-rows
+// from HBM with block_row_mv (bt_device.hpp).  Algorithmic bytes per problem:
+// ((3N-2) n^2 + 2 n N) sizeof(T)  (SURVEY.md section 8d).
+#include "bt_device.hpp"
+#include "internal.hpp"
+
+namespace gbdpcg {
+
+template <typename T, int NCT, int V, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_t rpw, uint32_t chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *xs = reinterpret_cast<T *>(smem_raw);
+
+    const uint32_t n = NCT ? (uint32_t)NCT : a.n;
+    const uint32_t N = a.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t prob = blockIdx.x / chunks;
+    const uint32_t chunk_id = blockIdx.x - prob * chunks;
+    const uint32_t k0 = chunk_id * rpw;
+    const uint32_t k1 = min(N, k0 + rpw);
+    const size_t len = (size_t)n * N;
+
+    // halo window [x_{k0-1} .. x_{k1}] with zeros outside the vector
+    const T *x = a.x + (size_t)prob * len;
+    const uint32_t cnt = (k1 - k0 + 2) * n;
+    const int64_t g0 = (int64_t)k0 * n - n;
+    for (uint32_t i = tid; i < cnt; i += WAVES * 64) {
+        const int64_t gi = g0 + i;
+        xs[i] = (gi >= 0 && gi < (int64_t)len) ? x[gi] : T(0);
+    }
+    __syncthreads();
+
+    const LaneMap<NCT, V> m(n, lane);
+    const T *M = a.M + (size_t)prob * 3 * n * n * N;
+    T *y = a.y + (size_t)prob * len;
+    for (uint32_t k = k0 + wave; k < k1; k += WAVES) {
+        T acc[V];
+        block_row_mv<T, NCT, V>(M + (size_t)k * 3 * n * n, xs + (k - k0) * n, m, lane,
+                                k == 0 ? n : 0u, k == N - 1 ? 2 * n : 3 * n, acc);
+        if (m.active && m.g == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) y[(size_t)k * n + m.rp * V + v] = acc[v];
+        }
+    }
+}
+
+template <typename T, int NCT, int V>
+static hipError_t launch_spmv_v(const DeviceInfo &dev, const SpmvArgs<T> &a, hipStream_t s)
+{
+    constexpr int WAVES = 4;
+    // ~8 workgroups per CU; every wave gets whole block-rows
+    const uint64_t total_rows = (uint64_t)a.N * a.batch;
+    const uint64_t target_wgs = (uint64_t)dev.num_cus * 8;
+    uint32_t rpw = (uint32_t)((total_rows + target_wgs - 1) / target_wgs);
+    rpw = (rpw + WAVES - 1) / WAVES * WAVES;
+    if (rpw > a.N) rpw = a.N;
+    if (rpw == 0) rpw = 1;
+    const uint32_t chunks = (a.N + rpw - 1) / rpw;
+    const size_t lds = (size_t)(rpw + 2) * a.n * sizeof(T);
+    if (lds > dev.lds_per_wg_max) return hipErrorInvalidValue;
+    auto kern = spmv_kernel<T, NCT, V, WAVES>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(chunks * a.batch), dim3(WAVES * 64), lds, s, a, rpw, chunks);
+    return hipGetLastError();
+}
+
+template <typename T, int NCT>
+static hipError_t launch_spmv_n(const DeviceInfo &dev, const SpmvArgs<T> &a, int V, hipStream_t s)
+{
+    // only instantiate (NCT, V) pairs choose_vec can produce
+    if (V == 1) return launch_spmv_v<T, NCT, 1>(dev, a, s);
+    if constexpr (NCT == 0 || NCT % 2 == 0) {
+        if (V == 2) return launch_spmv_v<T, NCT, 2>(dev, a, s);
+    }
+    if constexpr (sizeof(T) == 4 && (NCT == 0 || NCT % 4 == 0)) {
+        if (V == 4) return launch_spmv_v<T, NCT, 4>(dev, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename T> hipError_t launch_spmv(const DeviceInfo &dev, const SpmvArgs<T> &a, hipStream_t s)
+{
+    const void *ptrs[] = {a.M};
+    const int V = choose_vec<T>(a.n, ptrs, 1);
+    if (V == 0) return hipErrorInvalidValue;
+    switch (a.n) {
+    case 14: return launch_spmv_n<T, 14>(dev, a, V, s);
+    case 36: return launch_spmv_n<T, 36>(dev, a, V, s);
+    default: return launch_spmv_n<T, 0>(dev, a, V, s);
+    }
+}
+
+template hipError_t launch_spmv<float>(const DeviceInfo &, const SpmvArgs<float> &, hipStream_t);
+template hipError_t launch_spmv<double>(const DeviceInfo &, const SpmvArgs<double> &, hipStream_t);
+
+}  // namespace gbdpcg

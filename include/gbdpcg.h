@@ -1,0 +1,214 @@
+/*
+ * gbdpcg.h -- C ABI of libgbdpcg.so: MI355X-native (gfx950) block-tridiagonal PCG.
+ *
+ * This is the drop-in boundary for the solve path of A2R-Lab/GBD-PCG.  Every entry
+ * point cites the reference interface it replaces (paths relative to the reference
+ * checkout).  Plain pointers and sizes only; no C++ or torch types cross it.  The
+ * C++ surface the reference's callers see (solvePCG<T>, pcg_config<T>, ...) is the
+ * header-only wrapper include/gbdpcg.hpp, which forwards here.
+ *
+ * DATA LAYOUT (include/pcg.cuh:104-110, include/utils.cuh:80)
+ *   A block-tridiagonal matrix with N block-rows of n x n blocks is one array of
+ *   3*n*n*N elements: for knot k the three column-major blocks [L_k | D_k | R_k]
+ *   (block-row k, block-columns k-1, k, k+1); element (r,c) of block b lives at
+ *   k*3n^2 + b*n^2 + c*n + r.  L_0 and R_{N-1} are present but never read.
+ *   Vectors (gamma, lambda, r, p) have n*N elements.
+ *   A batch of `batch` independent problems is the problem-major concatenation of
+ *   the single-problem layout (matrix stride 3n^2N, vector stride nN).  The
+ *   reference has no batch notion: batch = 1 is its case.
+ *
+ * ERRORS
+ *   Every function returns a gbdpcg_status; nothing here prints or exits (the
+ *   reference's gpuErrchk / exit(code) convention, include/gpuassert.cuh:5-14, is
+ *   reproduced by the C++ wrapper).  Functions taking a stream are asynchronous and
+ *   capturable into a hipGraph: they never allocate, free or synchronise.
+ *
+ * There is no CPU fallback: without a gfx950 device gbdpcg_create fails with
+ * GBDPCG_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef GBDPCG_H
+#define GBDPCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gbdpcg_status {
+    GBDPCG_OK = 0,
+    GBDPCG_ERR_INVALID = 1,       /* bad argument (null pointer, n == 0, N == 0, ...) */
+    GBDPCG_ERR_HIP = 2,           /* a HIP runtime call failed; see gbdpcg_last_hip_error */
+    GBDPCG_ERR_NO_DEVICE = 3,     /* no usable gfx950 device */
+    GBDPCG_ERR_UNSUPPORTED = 4,   /* shape outside what this build supports */
+    GBDPCG_ERR_TOO_LARGE = 5,     /* checkPcgOccupancy analogue: does not fit on the device */
+    GBDPCG_ERR_ALLOC = 6,         /* workspace allocation failed */
+    GBDPCG_ERR_NOT_IMPLEMENTED = 12 /* the reference's exit code for its CSR stub (interface.cuh:18-19) */
+} gbdpcg_status;
+
+typedef struct gbdpcg_context *gbdpcg_handle_t;
+typedef struct gbdpcg_graph *gbdpcg_graph_t;
+
+/* Which execution strategy a solve uses.  AUTO picks by shape. */
+typedef enum gbdpcg_path {
+    GBDPCG_PATH_AUTO = 0,
+    GBDPCG_PATH_FUSED = 1, /* one workgroup per problem, vectors LDS-resident, one launch per solve */
+    GBDPCG_PATH_SPLIT = 2  /* many workgroups per problem, two launches per iteration, vectors in L2/HBM */
+} gbdpcg_path;
+
+/* Preconditioners gbdpcg_form_pinv can build from S. */
+typedef enum gbdpcg_pinv_kind {
+    GBDPCG_PINV_IDENTITY = 0,
+    GBDPCG_PINV_BLOCK_JACOBI = 1, /* diag blocks D_k^-1 */
+    GBDPCG_PINV_STAIR = 2         /* symmetric stair: D_k^-1, -D_k^-1 O_k D_{k+-1}^-1 */
+} gbdpcg_pinv_kind;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* One handle per host thread.  `device` is a HIP ordinal.  Allocates a few status words and
+ * pinned host words; replaces the per-call cudaMalloc/cudaFree of interface.cuh:105-108,140-141. */
+gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device);
+gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h);
+
+const char *gbdpcg_status_string(gbdpcg_status s);
+/* hipError_t (as int) of the last failing HIP call on this handle, and its string. */
+int gbdpcg_last_hip_error(gbdpcg_handle_t h);
+const char *gbdpcg_last_hip_error_string(gbdpcg_handle_t h);
+
+/* Force a path for subsequent solves on this handle (tests / benchmarks). */
+gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path);
+/* Path AUTO would take for this shape (elem_size 4 or 8). */
+gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
+                               uint32_t batch);
+
+/* ---- sizing helpers -------------------------------------------------------------------- */
+
+/* pcgSharedMemSize<T> (include/pcg.cuh:13-20): elem_size * max(6n^2 + 10n + 2max(n,N), 9n^2).
+ * Kept for callers that print / check it; this library sizes its own LDS. */
+size_t gbdpcg_pcg_shared_mem_size(uint32_t elem_size, uint32_t n, uint32_t N);
+
+/* checkPcgOccupancy<T> (include/pcg.cuh:23-49): GBDPCG_OK if a (n, N, batch) solve can run on
+ * the handle's device, GBDPCG_ERR_TOO_LARGE otherwise (the reference exits 5/6 instead). */
+gbdpcg_status gbdpcg_check_occupancy(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
+                                     uint32_t batch);
+
+/* Bytes of device workspace the SPLIT path needs for this shape (0 for FUSED).  The handle
+ * grows its own workspace on demand outside stream capture; call gbdpcg_reserve first when
+ * a solve will be captured into a caller-owned graph. */
+size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
+                              uint32_t batch);
+gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
+                             uint32_t batch);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* y = M x, block-tridiagonal, batched.  Replaces loadbdVec + bdmv (include/utils.cuh:9-85) as a
+ * standalone operator; this is the kernel the HBM-roofline target is quoted on.
+ * All pointers are device pointers; x and y must not alias. */
+gbdpcg_status gbdpcg_spmv_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                              const float *d_M, const float *d_x, float *d_y, void *stream);
+gbdpcg_status gbdpcg_spmv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                              const double *d_M, const double *d_x, double *d_y, void *stream);
+
+/* PCG solve of  Pinv S lambda = Pinv gamma  for `batch` independent problems.
+ * Replaces the kernel pcg<T,n,N> (include/pcg.cuh:54-218) and its launch
+ * (include/interface.cuh:110-133); same algorithm, same exit test (|eta_new| < tol, absolute),
+ * same outputs:
+ *   d_lambda  [batch*nN] in: initial guess, out: solution              (pcg.cuh:119,215)
+ *   d_r, d_p  [batch*nN] out: final residual / direction, may be NULL  (pcg.cuh:125,175,139,205)
+ *   d_iters   [batch]    out: iterations taken                         (pcg.cuh:212)
+ *   d_max_iter_exit [batch] out: 1 if the loop ran out, 0 if converged (pcg.cuh:212), may be NULL
+ * d_Pinv == NULL means the identity preconditioner.  The reference's scratch arguments
+ * d_v_temp / d_eta_new_temp (interface.cuh:101-102) have no counterpart: dot products are
+ * reduced on chip.  Asynchronous on `stream`; no host synchronisation. */
+gbdpcg_status gbdpcg_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                               const float *d_S, const float *d_Pinv, const float *d_gamma,
+                               float *d_lambda, float *d_r, float *d_p, float tol,
+                               uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit,
+                               void *stream);
+gbdpcg_status gbdpcg_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                               const double *d_S, const double *d_Pinv, const double *d_gamma,
+                               double *d_lambda, double *d_r, double *d_p, double tol,
+                               uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit,
+                               void *stream);
+
+/* Single-problem, blocking form of the device-pointer overload solvePCG<T>(state_size,
+ * knot_points, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, config)
+ * (include/interface.cuh:92-144): launches on the null stream, waits, returns the iteration
+ * count through *h_iters (what the reference returns at :143) and the max-iter flag the
+ * reference computes but never copies back (:107-108,141). */
+gbdpcg_status gbdpcg_solve_blocking_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N,
+                                        const float *d_S, const float *d_Pinv,
+                                        const float *d_gamma, float *d_lambda, float *d_r,
+                                        float *d_p, float tol, uint32_t max_iter,
+                                        uint32_t *h_iters, uint8_t *h_max_iter_exit);
+gbdpcg_status gbdpcg_solve_blocking_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N,
+                                        const double *d_S, const double *d_Pinv,
+                                        const double *d_gamma, double *d_lambda, double *d_r,
+                                        double *d_p, double tol, uint32_t max_iter,
+                                        uint32_t *h_iters, uint8_t *h_max_iter_exit);
+
+/* Host-pointer form of solvePCG<T>(h_S, h_gamma, h_lambda, stateSize, knotPoints, config)
+ * (include/interface.cuh:24-89): allocates device buffers, copies S / gamma / lambda in,
+ * solves, copies lambda out, frees.  Documented deviations from the reference, whose
+ * behaviour here is undefined (it never initialises Pinv, :45-46,57-59, and returns the
+ * constant 1, :88): h_Pinv == NULL means the identity preconditioner, and *h_iters receives
+ * the real iteration count. */
+gbdpcg_status gbdpcg_solve_host_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, const float *h_S,
+                                    const float *h_Pinv, const float *h_gamma, float *h_lambda,
+                                    float tol, uint32_t max_iter, uint32_t *h_iters,
+                                    uint8_t *h_max_iter_exit);
+gbdpcg_status gbdpcg_solve_host_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, const double *h_S,
+                                    const double *h_Pinv, const double *h_gamma, double *h_lambda,
+                                    double tol, uint32_t max_iter, uint32_t *h_iters,
+                                    uint8_t *h_max_iter_exit);
+
+/* ---- hipGraph-captured solves ---------------------------------------------------------- */
+
+/* Captures gbdpcg_solve_* with these exact arguments into an executable hipGraph (the
+ * "whole loop hipGraph-captured" of the north star).  MPC callers re-solve with the same
+ * buffers every control step: build once, gbdpcg_graph_launch per step. */
+gbdpcg_status gbdpcg_graph_create_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N,
+                                            uint32_t batch, const float *d_S, const float *d_Pinv,
+                                            const float *d_gamma, float *d_lambda, float *d_r,
+                                            float *d_p, float tol, uint32_t max_iter,
+                                            uint32_t *d_iters, uint8_t *d_max_iter_exit,
+                                            gbdpcg_graph_t *out);
+gbdpcg_status gbdpcg_graph_create_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N,
+                                            uint32_t batch, const double *d_S,
+                                            const double *d_Pinv, const double *d_gamma,
+                                            double *d_lambda, double *d_r, double *d_p, double tol,
+                                            uint32_t max_iter, uint32_t *d_iters,
+                                            uint8_t *d_max_iter_exit, gbdpcg_graph_t *out);
+gbdpcg_status gbdpcg_graph_launch(gbdpcg_graph_t g, void *stream);
+gbdpcg_status gbdpcg_graph_destroy(gbdpcg_graph_t g);
+
+/* ---- either side of the solve ---------------------------------- */
+
+/* Builds Pinv from S on the device (f1): the step the reference's host overload lacks
+ * (interface.cuh:33-34,45-46) and MPCGPU does with the block helpers of
+ * include/utils.cuh:96-161.  d_Pinv gets the same [L|D|R] layout as d_S. */
+gbdpcg_status gbdpcg_form_pinv_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                   const float *d_S, float *d_Pinv, gbdpcg_pinv_kind kind,
+                                   void *stream);
+gbdpcg_status gbdpcg_form_pinv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                   const double *d_S, double *d_Pinv, gbdpcg_pinv_kind kind,
+                                   void *stream);
+
+/* CSR ingestion (f3): repacks a host CSR matrix (csr_t<T>, include/types.cuh:7-15) whose
+ * sparsity lies inside the block-tridiagonal pattern into the [L|D|R] layout (host arrays).
+ * Entries outside the pattern give GBDPCG_ERR_INVALID.  Implements what the stub overload
+ * at include/interface.cuh:8-20 announces. */
+gbdpcg_status gbdpcg_csr_to_bt_f32(uint32_t n, uint32_t N, const uint32_t *row_ptr,
+                                   const uint32_t *col_ind, const float *val, float *h_M);
+gbdpcg_status gbdpcg_csr_to_bt_f64(uint32_t n, uint32_t N, const uint32_t *row_ptr,
+                                   const uint32_t *col_ind, const double *val, double *h_M);
+
+/* Library / build identification ("gbdpcg <version> gfx950"). */
+const char *gbdpcg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBDPCG_H */

@@ -1,0 +1,316 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (BASELINE.json north_star "lambda within 1e-6 relative of the
+reference at equal iteration count"):
+  fp64 : ||lambda - lambda_oracle||_2 / ||lambda_oracle||_2 <= 1e-10, equal iteration count
+  fp32 : <= 1e-6 norm-wise vs the fp32 oracle at equal iteration count (well-conditioned
+         generator, a = 0.5), and error vs the fp64 oracle <= 2x the fp32 oracle's own error
+  SpMV : fp64 <= 1e-13, fp32 <= 1e-6 norm-wise vs the dense fp64 product
+Bit-exactness is not claimed: the summation order inside the reference's GLASS primitives is
+unknown ("parity unpinned" at the last bit, oracle/pcg_oracle.c).
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from gbd_pcg_amd import binding, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-10
+F32_TOL = 1e-6
+PATHS = [binding.PATH_FUSED, binding.PATH_SPLIT]
+PATH_NAME = {binding.PATH_FUSED: "fused", binding.PATH_SPLIT: "split"}
+
+
+@pytest.fixture(scope="module")
+def solver():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    s = binding.Solver(0)
+    yield s
+    s.close()
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def gpu_solve(solver, n, N, batch, S, Pinv, gamma, lam0=None, tol=1e-6, max_iter=100, path=binding.PATH_AUTO):
+    solver.set_path(path)
+    dS, dg = dev(S), dev(gamma)
+    dP = None if Pinv is None else dev(Pinv)
+    lam = torch.zeros_like(dg) if lam0 is None else dev(lam0)
+    r, p = torch.empty_like(dg), torch.empty_like(dg)
+    iters, flags = solver.solve(n, N, batch, dS, dP, dg, lam, r, p, tol=tol, max_iter=max_iter)
+    torch.cuda.synchronize()
+    solver.set_path(binding.PATH_AUTO)
+    return dict(lambda_=lam.cpu().numpy().reshape(batch, -1), r=r.cpu().numpy().reshape(batch, -1),
+                p=p.cpu().numpy().reshape(batch, -1), iters=iters.cpu().numpy().astype(np.int64),
+                max_iter_exit=flags.cpu().numpy().astype(bool))
+
+
+# ------------------------------------------------------------------------------------- SpMV
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,N,batch", [(2, 3, 1), (3, 5, 2), (7, 2, 3), (14, 1, 2), (5, 9, 4), (14, 64, 1),
+                                       (14, 128, 8), (36, 256, 1), (16, 33, 2), (12, 40, 3), (64, 5, 1),
+                                       (37, 6, 2)])
+def test_spmv_vs_oracle_and_dense(solver, orc, dtype, n, N, batch):
+    d = synth.gen_numpy(n, N, seed=50, batch=batch, dtype=dtype)
+    x = np.stack([synth.normals(60 + b, 0, n * N) for b in range(batch)]).astype(dtype)
+    y = solver.spmv(n, N, batch, dev(d["S"]), dev(x))
+    torch.cuda.synchronize()
+    y = y.cpu().numpy()
+    yo = orc.spmv(n, N, d["S"], x, batch=batch).reshape(batch, -1)
+    tol = 1e-13 if dtype == np.float64 else F32_TOL
+    for b in range(batch):
+        A = orc.dense_from_bt(n, N, d["S"][b])
+        assert relerr(y[b], A @ x[b].astype(np.float64)) < tol
+        assert relerr(y[b], yo[b]) < tol
+
+
+def test_spmv_ignores_unused_corner_blocks(solver):
+    """L_0 / R_{N-1} are never read (pcg.cuh:105-106): NaNs there must not reach y."""
+    n, N, batch = 14, 6, 3
+    d = synth.gen_numpy(n, N, seed=51, batch=batch, dtype=np.float32)
+    x = np.stack([synth.normals(70 + b, 0, n * N) for b in range(batch)]).astype(np.float32)
+    y0 = solver.spmv(n, N, batch, dev(d["S"]), dev(x)).cpu().numpy()
+    S = d["S"].copy()
+    S[:, : n * n] = np.nan
+    S[:, -n * n:] = np.nan
+    y1 = solver.spmv(n, N, batch, dev(S), dev(x)).cpu().numpy()
+    assert np.array_equal(y0, y1)
+
+
+def test_spmv_linearity_full_size(solver):
+    """BASELINE config 3 at full size (n=14, N=128, batch=1024): S(ax + by) = a Sx + b Sy."""
+    n, N, batch = 14, 128, 1024
+    g = synth.gen_torch(n, N, batch, "cuda", torch.float32, seed=5)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((batch, n * N), device="cuda", generator=gen)
+    z = torch.randn((batch, n * N), device="cuda", generator=gen)
+    lhs = solver.spmv(n, N, batch, g["S"], (0.5 * x - 2.0 * z).contiguous())
+    rhs = 0.5 * solver.spmv(n, N, batch, g["S"], x) - 2.0 * solver.spmv(n, N, batch, g["S"], z)
+    torch.cuda.synchronize()
+    err = (lhs - rhs).norm(dim=1) / rhs.norm(dim=1)
+    assert float(err.max()) < 2e-6
+    # symmetry of S: x.(S z) == z.(S x)
+    a = (x.double() * solver.spmv(n, N, batch, g["S"], z).double()).sum(1)
+    b = (z.double() * solver.spmv(n, N, batch, g["S"], x).double()).sum(1)
+    assert float(((a - b).abs() / (a.abs() + b.abs() + 1e-30)).max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------- PCG
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+def test_readme_system_fp64(solver, orc, golden_dir, path):
+    """BASELINE config 1 shape (n=2, N=3, fp64): the reference's example system
+    (examples/pcg_solve_dp.cu:14-25) -> dense answer, 6 iterations with Pinv = I, 3 with the stair."""
+    G = np.load(os.path.join(golden_dir, "readme.npz"))
+    n, N, S, gamma = orc.readme_system()
+    out = gpu_solve(solver, n, N, 1, S, None, gamma, tol=1e-6, max_iter=25, path=path)
+    assert out["iters"][0] == 6 == int(G["iters_f64_ident"]) and not out["max_iter_exit"][0]
+    assert relerr(out["lambda_"][0], G["lambda_dense"]) < 1e-10
+    assert relerr(out["lambda_"][0], G["lambda_f64_ident"]) < F64_TOL
+    L, D, R = synth.unpack_bt(n, N, S)
+    P = synth.pack_bt(*synth.stair_pinv_blocks(L, D, R))
+    out = gpu_solve(solver, n, N, 1, S, P, gamma, tol=1e-6, max_iter=25, path=path)
+    assert out["iters"][0] == 3 and relerr(out["lambda_"][0], G["lambda_f64_stair"]) < F64_TOL
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+def test_readme_system_fp32(solver, orc, path):
+    """fp32 twin (examples/pcg_solve.cu:14-25) with the stair preconditioner: 3 iterations under
+    every summation order; kappa ~ 1562 so the answer is good to ~1e-5."""
+    n, N, S, gamma = orc.readme_system()
+    L, D, R = synth.unpack_bt(n, N, S)
+    P = synth.pack_bt(*synth.stair_pinv_blocks(L, D, R))
+    lam = np.linalg.solve(orc.dense_from_bt(n, N, S), gamma)
+    out = gpu_solve(solver, n, N, 1, S.astype(np.float32), P.astype(np.float32), gamma.astype(np.float32),
+                    max_iter=25, path=path)
+    assert out["iters"][0] == 3 and relerr(out["lambda_"][0], lam) < 5e-5
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+@pytest.mark.parametrize("name", ["gen_2x3", "gen_3x5", "gen_7x2", "gen_14x1", "gen_14x64", "gen_14x128",
+                                  "gen_36x256"])
+@pytest.mark.parametrize("pinv", ["stair", "ident"])
+def test_golden_fp64(solver, golden_dir, path, name, pinv):
+    """Committed fixtures (tests/golden): fp64 lambda <= 1e-10 of the oracle's, equal iterations.
+    gen_14x64 / gen_14x128 / gen_36x256 are BASELINE configs 2 / 3 (one problem) / 4."""
+    G = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, N = int(G["n"]), int(G["N"])
+    d = synth.gen_numpy(n, N, seed=int(G["seed"]), a=float(G["a"]))
+    P = d["Pinv"] if pinv == "stair" else None
+    out = gpu_solve(solver, n, N, 1, d["S"], P, d["gamma"], tol=1e-6, max_iter=100, path=path)
+    assert out["iters"][0] == int(G[f"iters_f64_{pinv}"]) and not out["max_iter_exit"][0]
+    assert relerr(out["lambda_"][0], G[f"lambda_f64_{pinv}"]) < F64_TOL
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+@pytest.mark.parametrize("n,N", [(14, 64), (14, 128), (36, 256), (3, 5), (2, 3)])
+def test_fp32_vs_oracle(solver, orc, golden_dir, path, n, N):
+    """fp32: <= 1e-6 norm-wise vs the fp32 oracle at equal iteration count, and no worse than 2x the
+    fp32 oracle's own distance from the fp64 oracle (BASELINE configs 2, 3 (one problem), 4 in fp32)."""
+    G = np.load(os.path.join(golden_dir, f"gen_{n}x{N}.npz"))
+    d = synth.gen_numpy(n, N, seed=1234, a=0.5, dtype=np.float32)
+    o32 = orc.pcg(n, N, d["S"][0], d["Pinv"][0], d["gamma"][0], tol=1e-6, max_iter=100)
+    out = gpu_solve(solver, n, N, 1, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100, path=path)
+    assert out["iters"][0] == o32["iters"] == int(G["iters_f32_stair"])
+    assert relerr(out["lambda_"][0], o32["lambda_"]) < F32_TOL
+    ref64 = G["lambda_f64_stair"]
+    assert relerr(out["lambda_"][0], ref64) < 2 * relerr(o32["lambda_"], ref64) + 1e-7
+    # final r and p are left behind for the caller (pcg.cuh:175,205); at convergence they are
+    # rounding-sized, so compare on the scale of gamma
+    gnorm = np.linalg.norm(d["gamma"][0])
+    assert np.linalg.norm(out["r"][0] - o32["r"]) < 1e-5 * gnorm
+    assert np.linalg.norm(out["p"][0] - o32["p"]) < 1e-5 * gnorm
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batch_of_config3(solver, orc, golden_dir, path, dtype):
+    """G6: eight problems of BASELINE config 3's batch (seeds 1234+i), solved as one batch."""
+    G = np.load(os.path.join(golden_dir, "gen_14x128_batch8.npz"))
+    n, N, B = 14, 128, 8
+    d = synth.gen_numpy(n, N, seed=1234, batch=B, dtype=dtype)
+    out = gpu_solve(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100, path=path)
+    assert np.array_equal(out["iters"], G["iters_f64_stair"]) and not out["max_iter_exit"].any()
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    for b in range(B):
+        if dtype == np.float64:
+            assert relerr(out["lambda_"][b], G["lambda_f64_stair"][b]) < F64_TOL
+        else:
+            assert relerr(out["lambda_"][b], ob["lambda_"][b]) < F32_TOL
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fixed_iteration_state(solver, orc, path, dtype):
+    """exit_tol = 0, max_iter = k: exactly k iterations (abs(eta) < 0 never holds, pcg.cuh:195),
+    max_iter_exit set, and lambda, r, p all match the oracle's state after k iterations."""
+    n, N, B = 14, 20, 3
+    d = synth.gen_numpy(n, N, seed=77, batch=B, dtype=dtype)
+    for k in (0, 1, 2, 5):
+        out = gpu_solve(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=k, path=path)
+        ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=k)
+        assert (out["iters"] == k).all() and out["max_iter_exit"].all()
+        tol = 1e-10 if dtype == np.float64 else 1e-5
+        for key in ("lambda_", "r", "p"):
+            for b in range(B):
+                # r and p shrink as the solve proceeds: measure them on the scale of gamma
+                scale = max(np.linalg.norm(ob[key][b]), 1e-2 * np.linalg.norm(d["gamma"][b]))
+                if key == "lambda_" and k == 0:
+                    assert not out[key][b].any()
+                    continue
+                assert np.linalg.norm(out[key][b].astype(np.float64) - ob[key][b]) < tol * scale, (k, key, b)
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+def test_ragged_convergence_in_one_batch(solver, orc, path):
+    """Problems of one batch exit at their own iteration counts: a warm-started problem (1
+    iteration), a harder one (a = 0.9) and a capped one share a launch."""
+    n, N = 14, 24
+    easy = synth.gen_numpy(n, N, seed=5, a=0.5)
+    hard = synth.gen_numpy(n, N, seed=6, a=0.9)
+    S = np.concatenate([easy["S"], hard["S"], easy["S"]])
+    P = np.concatenate([easy["Pinv"], hard["Pinv"], easy["Pinv"]])
+    g = np.concatenate([easy["gamma"], hard["gamma"], easy["gamma"]])
+    lam_star = np.linalg.solve(orc.dense_from_bt(n, N, easy["S"][0]), easy["gamma"][0])
+    lam0 = np.zeros_like(g)
+    lam0[2] = lam_star
+    out = gpu_solve(solver, n, N, 3, S, P, g, lam0=lam0, tol=1e-6, max_iter=20, path=path)
+    ob = [orc.pcg(n, N, S[b], P[b], g[b], lambda0=lam0[b], tol=1e-6, max_iter=20) for b in range(3)]
+    assert [o["iters"] for o in ob] == list(out["iters"])
+    assert out["iters"][2] == 1 and out["iters"][1] == 20 and out["max_iter_exit"][1]
+    assert not out["max_iter_exit"][0] and not out["max_iter_exit"][2]
+    for b in range(3):
+        assert relerr(out["lambda_"][b], ob[b]["lambda_"]) < F64_TOL
+
+
+def test_auto_path_choice(solver):
+    """BASELINE configs: 2 and 3 run fused (vectors fit one workgroup's LDS), 4 must run split."""
+    assert solver.choose_path(4, 14, 64, 1) == binding.PATH_FUSED
+    assert solver.choose_path(4, 14, 128, 1024) == binding.PATH_FUSED
+    assert solver.choose_path(8, 36, 256, 1) == binding.PATH_SPLIT
+
+
+def test_blocking_and_host_overloads(solver, orc, golden_dir):
+    """The two reference entry points: device-pointer overload (interface.cuh:92-144) returns the
+    iteration count; host overload (interface.cuh:24-89) with Pinv = NULL means identity."""
+    G = np.load(os.path.join(golden_dir, "readme.npz"))
+    n, N, S, gamma = orc.readme_system()
+    dS, dg = dev(S), dev(gamma)
+    lam = torch.zeros_like(dg)
+    it, flag = solver.solve_blocking(n, N, dS, None, dg, lam, tol=1e-6, max_iter=25)
+    assert it == 6 and not flag and relerr(lam.cpu().numpy(), G["lambda_dense"]) < 1e-10
+    h_lam = np.zeros(n * N)
+    it, flag = solver.solve_host(n, N, S, None, gamma, h_lam, tol=1e-6, max_iter=25)
+    assert it == 6 and not flag and relerr(h_lam, G["lambda_dense"]) < 1e-10
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+def test_graph_replay(solver, orc, path):
+    """hipGraph-captured solve: replay gives the same lambda as the eager launch, every time."""
+    n, N, B = 14, 16, 4
+    d = synth.gen_numpy(n, N, seed=31, batch=B, dtype=np.float64)
+    eager = gpu_solve(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=30, path=path)
+    solver.set_path(path)
+    dS, dP, dg = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+    lam = torch.zeros_like(dg)
+    r, p = torch.empty_like(dg), torch.empty_like(dg)
+    iters = torch.zeros(B, dtype=torch.int32, device="cuda")
+    flags = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    g = solver.graph_solve(n, N, B, dS, dP, dg, lam, r, p, 1e-6, 30, iters, flags)
+    solver.set_path(binding.PATH_AUTO)
+    for _ in range(3):
+        lam.zero_()
+        g.launch()
+        torch.cuda.synchronize()
+        assert np.array_equal(lam.cpu().numpy().reshape(B, -1), eager["lambda_"])
+        assert np.array_equal(iters.cpu().numpy(), eager["iters"])
+    g.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["stair", "jacobi", "identity"])
+def test_form_pinv(solver, dtype, kind):
+    """f1: Pinv built on the device from S equals the host construction."""
+    n, N, B = 14, 9, 3
+    d = synth.gen_numpy(n, N, seed=41, batch=B, dtype=dtype, pinv=kind)
+    code = {"stair": binding.PINV_STAIR, "jacobi": binding.PINV_BLOCK_JACOBI, "identity": binding.PINV_IDENTITY}[kind]
+    P = solver.form_pinv(n, N, B, dev(d["S"]), code)
+    torch.cuda.synchronize()
+    P = P.cpu().numpy().reshape(B, N, 3, n * n).copy()
+    want = d["Pinv"].reshape(B, N, 3, n * n).copy()
+    # the never-read corner slots are unspecified
+    for arr in (P, want):
+        arr[:, 0, 0] = 0
+        arr[:, -1, 2] = 0
+    assert relerr(P, want) < (1e-12 if dtype == np.float64 else 1e-5)
+
+
+def test_full_size_config3_properties(solver):
+    """BASELINE config 3 at full size (n=14, N=128, batch=1024, fp32): every problem converges in
+    the generator's 9-10 iterations and the true residual ||gamma - S lambda|| / ||gamma|| is at
+    the fp32 level; a second solve warm-started at the solution exits after one iteration."""
+    n, N, B = 14, 128, 1024
+    g = synth.gen_torch(n, N, B, "cuda", torch.float32, seed=11)
+    lam = torch.zeros_like(g["gamma"])
+    iters, flags = solver.solve(n, N, B, g["S"], g["Pinv"], g["gamma"], lam, tol=1e-6, max_iter=50)
+    torch.cuda.synchronize()
+    it = iters.cpu().numpy()
+    assert flags.sum().item() == 0 and it.min() >= 7 and it.max() <= 12
+    res = g["gamma"] - solver.spmv(n, N, B, g["S"], lam)
+    rel = res.norm(dim=1) / g["gamma"].norm(dim=1)
+    assert float(rel.max()) < 5e-4
+    iters2, _ = solver.solve(n, N, B, g["S"], g["Pinv"], g["gamma"], lam, tol=1e-6, max_iter=50)
+    torch.cuda.synchronize()
+    assert int(iters2.max()) == 1
