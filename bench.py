@@ -48,12 +48,24 @@ def spmv_bytes_per_launch(n, N, batch, s):
     return batch * ((3 * N - 2) * n * n + 2 * n * N) * s
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(n, N, iters, budget_s=12.0):
     """Oracle (port) on the host cores, bounded sample of the same workload."""
     import numpy as np
     from gbd_pcg_amd import synth
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     probe = max(cores, 8)
     d = synth.gen_numpy(n, N, seed=1234, batch=probe, dtype=np.float32)
     t0 = time.perf_counter()
@@ -144,14 +156,18 @@ def main():
     for _ in range(4):
         solver.spmv(n, N, B, S, x, y)
         solver.spmv(n, N, B, P, x, y)
-    sp_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    # back-to-back launches between one event pair per round: a 60 us kernel is shorter than the
+    # host launch path, so per-launch event brackets would time the host, not the kernel
+    SP_LAUNCHES, SP_ROUNDS = 20, 5
+    sp_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SP_ROUNDS)]
     torch.cuda.synchronize()
-    for k, (a, b) in enumerate(sp_ev):
+    for a, b in sp_ev:
         a.record(stream)
-        solver.spmv(n, N, B, S if k % 2 == 0 else P, x, y)
+        for k in range(SP_LAUNCHES):
+            solver.spmv(n, N, B, S if k % 2 == 0 else P, x, y)
         b.record(stream)
     torch.cuda.synchronize()
-    sp_ms = sorted(a.elapsed_time(b) for a, b in sp_ev)[len(sp_ev) // 2]
+    sp_ms = sorted(a.elapsed_time(b) for a, b in sp_ev)[len(sp_ev) // 2] / SP_LAUNCHES
     sp_gbps = spmv_bytes_per_launch(n, N, B, 4) / (sp_ms * 1e-3) / 1e9
 
     if rank == 0:

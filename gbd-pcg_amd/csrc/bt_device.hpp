@@ -1,7 +1,7 @@
 // bt_device.hpp -- wavefront-level primitives for block-tridiagonal [L|D|R] matrices (gfx950).
 //
 // What replaces what (reference paths relative to /root/reference):
-//   block_row_mv   <- loadbdVec + bdmv              (include/utils.cuh:9-85)
+//   stream_rows    <- loadbdVec + bdmv              (include/utils.cuh:9-85)
 //   wave_sum       <- glass::dot / glass::reduce    (call sites include/pcg.cuh:144-149,163-169,187-193)
 //
 // Design (not a translation).  The reference gives one CUDA block to a knot and lets thread r
@@ -14,11 +14,14 @@
 //               contiguous chunk of G*n elements; lane l reads elements [l*V, l*V+V) of it
 //
 // so every load instruction is a dense, ascending V*sizeof(T)-byte-per-lane access (8 B for
-// n = 14 fp32 with 63/64 lanes live; 16 B for n = 36 fp64), each lane keeps ONE fixed row set
-// and accumulates over columns in registers, and only a log2(G) shuffle tree is needed per
+// n = 14 fp32 with 63/64 lanes live -- measured at the read ceiling of the chip, see
+// profiles/r01_bw_probe_*.txt; 16 B for n = 36 fp64), each lane keeps ONE fixed row set and
+// accumulates over columns in registers, and only a log2(G) shuffle tree is needed per
 // block-row.  The x operand ([x_{k-1}; x_k; x_{k+1}], 3n values) is read from LDS as G
-// broadcast addresses per step.  MFMA is not used: the contraction is a GEMV with
-// arithmetic intensity ~0.5 flop/B, bounded by HBM.
+// broadcast addresses per step.  Loads are software-pipelined through a register ring of
+// DEPTH units (a unit = a group of steps) so a wave always has DEPTH-1 units in flight while
+// it multiplies and reduces the oldest one.  MFMA is not used: the contraction is a GEMV with arithmetic intensity
+// ~0.5 flop/B, bounded by HBM.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,6 +30,11 @@
 namespace gbdpcg {
 
 constexpr uint32_t kWave = 64;
+
+// One correctly-rounded fused multiply-add in T's own precision.  (__builtin_fma is the DOUBLE
+// builtin: given floats it converts, does an fp64 FMA and rounds back -- slow and not fp32 math.)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <typename T, int V> struct VecOf;
 template <> struct VecOf<float, 1> { using type = float; };
@@ -81,49 +89,95 @@ template <int NCT, int V> struct LaneMap {
     }
 };
 
-// One block-row times [x_{k-1}; x_k; x_{k+1}].
-//   Mk   : global, the 3n^2 elements of block-row k
-//   xk   : LDS, xk[c] multiplies column c (c in [0,3n)); only c in [c_lo, c_hi) is touched
-//          (c_lo = n for k = 0, c_hi = 2n for k = N-1: L_0 / R_{N-1} are never read,
-//          include/pcg.cuh:105-106, include/utils.cuh:58-75)
-// On return lanes with g == 0 (and active) hold y_k[rp*V + v] in acc[v]; other lanes hold junk.
-template <typename T, int NCT, int V>
-__device__ __forceinline__ void block_row_mv(const T *__restrict__ Mk, const T *xk,
-                                             const LaneMap<NCT, V> &m, uint32_t lane,
-                                             uint32_t c_lo, uint32_t c_hi, T (&acc)[V])
-{
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = T(0);
+// Compile-time geometry of the pipelined stream (NCT > 0 only).
+template <typename T, int NCT, int V> struct StreamGeom {
+    static constexpr uint32_t N_ = NCT > 0 ? NCT : 1;
+    static constexpr uint32_t RPC = N_ / V > 0 ? N_ / V : 1;
+    static constexpr uint32_t G = kWave / RPC > 0 ? kWave / RPC : 1;
+    static constexpr uint32_t STEPS = (3 * N_ + G - 1) / G;
+    // a unit = CH steps held in registers at once; keep a unit at <= ~24 VGPRs per lane
+    static constexpr uint32_t REGS_PER_STEP = V * sizeof(T) / 4;
+    static constexpr uint32_t CH_MAX = 24 / REGS_PER_STEP > 0 ? 24 / REGS_PER_STEP : 1;
+    static constexpr uint32_t UPR = (STEPS + CH_MAX - 1) / CH_MAX;  // units per row
+    static constexpr uint32_t CH = (STEPS + UPR - 1) / UPR;         // steps per unit (balanced)
+    // ring depth: ~40-72 VGPRs of matrix data in flight per lane
+    static constexpr int DEPTH = CH * REGS_PER_STEP <= 12 ? 4 : 3;
+};
 
-    const uint32_t chunk = m.G * m.n;  // elements per step
-    const T *src = Mk + lane * V;
-    if (NCT) {
+template <typename T, int NCT, int V> struct StreamUnit {
+    T a[StreamGeom<T, NCT, V>::CH][V];
+};
+
+// Per-lane constants of the pipelined stream: two element offsets and two x columns, so that
+// every load of a unit is `scalar row base + one of two VGPR offsets + immediate`.
+//   * lanes outside the map (lane >= G*rpc) read element 0 of the step instead of running past it
+//   * on the ragged last step (3n % G != 0) lanes whose column would leave the block-row read
+//     element 0 as well and are zeroed in fma_unit
+// Lanes outside the map compute junk that fold_groups never picks up.
+template <typename T, int NCT, int V> struct StreamCtx {
+    using Gm = StreamGeom<T, NCT, V>;
+    static constexpr bool RAGGED = (3 * Gm::N_) % Gm::G != 0;
+    uint32_t off_lane, off_last;  // element offsets inside a step chunk
+    uint32_t xcol, xcol_last;     // x column read at step 0 / at the last step (clamped into the row)
+    bool ok_last;                 // this lane's column of the last step is inside the block-row
+    __device__ __forceinline__ StreamCtx(const LaneMap<NCT, V> &m, uint32_t lane) {
+        const uint32_t c_last = m.g + Gm::G * (Gm::STEPS - 1);
+        ok_last = m.active && c_last < 3 * Gm::N_;
+        off_lane = m.active ? lane * V : 0u;
+        off_last = ok_last ? lane * V : 0u;
+        xcol = m.active ? m.g : 0u;
+        xcol_last = ok_last ? c_last : 3 * Gm::N_ - 1;
+    }
+};
+
+// Issue the loads of unit u of the block-row at Mk: CH back-to-back load instructions, no branches.
+template <typename T, int NCT, int V>
+__device__ __forceinline__ void load_unit(const T *__restrict__ Mk, uint32_t u, const StreamCtx<T, NCT, V> &cx,
+                                          StreamUnit<T, NCT, V> &t)
+{
+    using Gm = StreamGeom<T, NCT, V>;
 #pragma unroll
-        for (uint32_t s = 0; s < m.steps; ++s) {
-            const uint32_t c = m.g + m.G * s;
-            if (m.active && c >= c_lo && c < c_hi) {
-                T a[V];
-                VecIO<T, V>::load(src + s * chunk, a);
-                const T xv = xk[c];
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc[v] = __builtin_fma(a[v], xv, acc[v]);
-            }
-        }
-    } else {
-#pragma unroll 4
-        for (uint32_t s = 0; s < m.steps; ++s) {
-            const uint32_t c = m.g + m.G * s;
-            if (m.active && c >= c_lo && c < c_hi) {
-                T a[V];
-                VecIO<T, V>::load(src + s * chunk, a);
-                const T xv = xk[c];
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc[v] = __builtin_fma(a[v], xv, acc[v]);
-            }
+    for (uint32_t j = 0; j < Gm::CH; ++j) {
+        const uint32_t s = u * Gm::CH + j;
+        if (Gm::STEPS % Gm::CH == 0 || s < Gm::STEPS) {
+            const uint32_t off = (StreamCtx<T, NCT, V>::RAGGED && s == Gm::STEPS - 1) ? cx.off_last : cx.off_lane;
+            VecIO<T, V>::load(Mk + s * (Gm::G * Gm::N_) + off, t.a[j]);
         }
     }
+}
 
-    // fold the G column-groups: halving tree over g with a lane stride of rpc
+// acc += unit * x for the row whose x window starts at xk (xk[c] multiplies column c).
+// EDGE rows (k = 0 or k = N-1) additionally zero the columns outside [c_lo, c_hi): L_0 / R_{N-1}
+// may hold anything and must not reach the result (pcg.cuh:105-106, utils.cuh:58-75).
+template <typename T, int NCT, int V, bool EDGE>
+__device__ __forceinline__ void fma_unit(const StreamUnit<T, NCT, V> &t, uint32_t u, const T *xk,
+                                         const StreamCtx<T, NCT, V> &cx, uint32_t g, uint32_t c_lo, uint32_t c_hi,
+                                         T (&acc)[V])
+{
+    using Gm = StreamGeom<T, NCT, V>;
+    const T *xg = xk + cx.xcol;
+#pragma unroll
+    for (uint32_t j = 0; j < Gm::CH; ++j) {
+        const uint32_t s = u * Gm::CH + j;
+        if (Gm::STEPS % Gm::CH == 0 || s < Gm::STEPS) {
+            const bool last = StreamCtx<T, NCT, V>::RAGGED && s == Gm::STEPS - 1;
+            const T xv = last ? xk[cx.xcol_last] : xg[Gm::G * s];
+            bool keep = last ? cx.ok_last : true;
+            if (EDGE) {
+                const uint32_t c = g + Gm::G * s;
+                keep = keep && c >= c_lo && c < c_hi;
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fma_t((EDGE || last) ? (keep ? t.a[j][v] : T(0)) : t.a[j][v], xv, acc[v]);
+        }
+    }
+}
+
+// Fold the G column-groups: halving tree over g with a lane stride of rpc.  Afterwards lanes
+// with g == 0 (and active) hold the row values.
+template <typename T, int NCT, int V>
+__device__ __forceinline__ void fold_groups(const LaneMap<NCT, V> &m, T (&acc)[V])
+{
     uint32_t size = m.G;
     for (uint32_t off = pow2_ceil(m.G) >> 1; off >= 1; off >>= 1) {
 #pragma unroll
@@ -132,6 +186,124 @@ __device__ __forceinline__ void block_row_mv(const T *__restrict__ Mk, const T *
             if (m.g < off && m.g + off < size) acc[v] += other;
         }
         size = off;
+    }
+}
+
+// Non-pipelined block-row product for runtime n (NCT == 0).
+template <typename T, int V>
+__device__ __forceinline__ void block_row_mv_rt(const T *__restrict__ Mk, const T *xk, const LaneMap<0, V> &m,
+                                                uint32_t lane, uint32_t c_lo, uint32_t c_hi, T (&acc)[V])
+{
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = T(0);
+    const uint32_t chunk = m.G * m.n;
+    const T *src = Mk + lane * V;
+#pragma unroll 4
+    for (uint32_t s = 0; s < m.steps; ++s) {
+        const uint32_t c = m.g + m.G * s;
+        if (m.active && c >= c_lo && c < c_hi) {
+            T a[V];
+            VecIO<T, V>::load(src + s * chunk, a);
+            const T xv = xk[c];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fma_t(a[v], xv, acc[v]);
+        }
+    }
+}
+
+// Stream the block-rows k = k_begin, k_begin + k_step, ... < k_end of one problem through this
+// wavefront.  M is the problem's matrix base; row k multiplies the LDS window xw + (k - k_x0)*n
+// (xw[c] for column c of row k_x0, zero-padded by the caller where the vector ends).
+// on_row(k, acc) is called by every lane after each row; lanes with g == 0 && active hold
+// y_k[rp*V + v] in acc[v].
+//
+// NCT > 0: the wave's rows are cut into units (StreamGeom) numbered q = 0, 1, ...; a ring of
+// DEPTH register-resident units keeps DEPTH-1 units of loads in flight behind the one being
+// multiplied (loads return in order, so the compiler's counted vmcnt waits only for the oldest).
+// The ring slot is a compile-time index (the loop is unrolled by DEPTH); row and unit-in-row
+// are runtime values that only enter address arithmetic.
+template <typename T, int NCT, int V, int DEPTH, typename RowFn>
+__device__ __forceinline__ void stream_rows(const T *__restrict__ M, const T *xw, uint32_t k_x0, uint32_t k_begin,
+                                            uint32_t k_end, uint32_t k_step, uint32_t N, const LaneMap<NCT, V> &m,
+                                            uint32_t lane, RowFn &&on_row)
+{
+    const uint32_t n = m.n;
+    const size_t row_elems = (size_t)3 * n * n;
+    if constexpr (NCT > 0) {
+        using Gm = StreamGeom<T, NCT, V>;
+        StreamUnit<T, NCT, V> ring[DEPTH];
+        const StreamCtx<T, NCT, V> cx(m, lane);
+        const uint32_t nrows = k_end > k_begin ? (k_end - k_begin + k_step - 1) / k_step : 0;
+        const uint32_t total = nrows * Gm::UPR;
+        // (kept as a macro-like inline block: a by-reference lambda here would not be inlined at
+        // every call site and the ring would fall out of registers into scratch)
+#define GBDPCG_ISSUE(q_, slot_)                                                                         \
+    do {                                                                                                \
+        const uint32_t ri_ = (q_) / Gm::UPR, u_ = (q_) - ri_ * Gm::UPR;                                 \
+        load_unit<T, NCT, V>(M + (k_begin + ri_ * k_step) * row_elems, u_, cx, (slot_));                \
+    } while (0)
+        T acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = T(0);
+        // multiply unit q out of ring slot j_, optionally refill the slot with unit q + DEPTH
+#define GBDPCG_CONSUME(q_, j_, refill_)                                                                 \
+    do {                                                                                                \
+        const uint32_t ri = (q_) / Gm::UPR, u = (q_) - ri * Gm::UPR;                                    \
+        const uint32_t k = k_begin + ri * k_step;                                                       \
+        const T *xk = xw + (k - k_x0) * n;                                                              \
+        if (k == 0 || k == N - 1) { /* wave-uniform */                                                  \
+            fma_unit<T, NCT, V, true>(ring[j_], u, xk, cx, m.g, k == 0 ? n : 0u,                        \
+                                      k == N - 1 ? 2 * n : 3 * n, acc);                                 \
+        } else {                                                                                        \
+            fma_unit<T, NCT, V, false>(ring[j_], u, xk, cx, m.g, 0u, 3 * n, acc);                       \
+        }                                                                                               \
+        if (refill_) GBDPCG_ISSUE((q_) + DEPTH, ring[j_]);                                              \
+        if (Gm::UPR == 1 || u == Gm::UPR - 1) {                                                         \
+            fold_groups<T, NCT, V>(m, acc);                                                             \
+            on_row(k, acc);                                                                             \
+            _Pragma("unroll") for (int v = 0; v < V; ++v) acc[v] = T(0);                                \
+        }                                                                                               \
+    } while (0)
+        // Steady state: the ring is primed unconditionally and every consumed slot is refilled, with
+        // no data-dependent control flow around the loads, so the compiler's counted vmcnt waits see
+        // exactly DEPTH-1 younger units in flight.  (A conditionally primed ring would make the
+        // waitcnt pass assume the shortest queue at the loop header and drain it every iteration.)
+        uint32_t q0 = 0;
+        if (total >= 2 * DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                GBDPCG_ISSUE((uint32_t)j, ring[j]);
+                // keep the units' loads in issue order: the loop's counted waits assume it
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            do {
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) GBDPCG_CONSUME(q0 + j, j, true);
+                q0 += DEPTH;
+            } while (q0 + 2 * DEPTH <= total);
+        } else {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                if ((uint32_t)j < total) GBDPCG_ISSUE((uint32_t)j, ring[j]);
+        }
+        // drain: at most 2*DEPTH-1 units left
+        for (; q0 < total; q0 += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                const uint32_t q = q0 + j;
+                if (q < total) GBDPCG_CONSUME(q, j, q + DEPTH < total);
+            }
+        }
+#undef GBDPCG_CONSUME
+#undef GBDPCG_ISSUE
+    } else {
+        for (uint32_t k = k_begin; k < k_end; k += k_step) {
+            T acc[V];
+            block_row_mv_rt<T, V>(M + k * row_elems, xw + (k - k_x0) * n, m, lane, k == 0 ? n : 0u,
+                                  k == N - 1 ? 2 * n : 3 * n, acc);
+            fold_groups<T, NCT, V>(m, acc);
+            on_row(k, acc);
+        }
     }
 }
 

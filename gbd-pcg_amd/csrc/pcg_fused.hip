@@ -6,13 +6,15 @@
 // 4-26 us (MI355X_MICROARCH.md, barrier-xcd / barrier-cg), so this kernel turns the
 // decomposition around: the VECTORS (lambda, r, p, and the S p / Pinv r product) of one
 // problem live in one workgroup's LDS for the whole solve, S and Pinv are streamed from HBM
-// once per iteration by block_row_mv, and both inner products are reduced inside the
+// once per iteration by stream_rows, and both inner products are reduced inside the
 // workgroup (wave butterfly -> WAVES partials in LDS -> same-order sum in every thread, which
 // keeps the convergence branch uniform like pcg.cuh:147,167,191 do).  No cross-CU traffic at
 // all; each problem exits on its own iteration count.  Algorithmic HBM bytes per
 // problem-iteration: 2 (3N-2) n^2 sizeof(T)  (SURVEY.md section 8d).
 //
 // Iteration restated from pcg.cuh:118-208 (see oracle/pcg_oracle_impl.inc for the sequential form).
+#include <cstdlib>
+
 #include "bt_device.hpp"
 #include "internal.hpp"
 
@@ -45,19 +47,16 @@ __device__ __forceinline__ T wg_spmv_dot(const T *__restrict__ M, const T *X, T 
                                          uint32_t lane, uint32_t wave)
 {
     T part = T(0);
-    for (uint32_t k = wave; k < N; k += WAVES) {
-        T acc[V];
-        block_row_mv<T, NCT, V>(M + (size_t)k * 3 * n * n, X + k * n, m, lane, k == 0 ? n : 0u,
-                                k == N - 1 ? 2 * n : 3 * n, acc);
+    stream_rows<T, NCT, V, StreamGeom<T, NCT, V>::DEPTH>(M, X, 0u, wave, N, WAVES, N, m, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
         if (m.active && m.g == 0) {
             const uint32_t row = k * n + m.rp * V;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 Y[row + v] = acc[v];
-                part = __builtin_fma(acc[v], D[n + row + v], part);
+                part = fma_t(acc[v], D[n + row + v], part);
             }
         }
-    }
+    });
     return part;
 }
 
@@ -85,7 +84,8 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     const uint32_t n = NCT ? (uint32_t)NCT : a.n;
     const uint32_t N = a.N;
     const uint32_t len = n * N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps row bases in SGPRs
     const FusedCarve<T> cv(n, N, WAVES);
     T *xa = smem + cv.xa, *xb = smem + cv.xb, *yc = smem + cv.yc, *lam = smem + cv.lam;
     T *red0 = smem + cv.red, *red1 = red0 + WAVES;
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
         const T *gamma = a.gamma + (size_t)prob * len;
         T *lambda = a.lambda + (size_t)prob * len;
 
-        // ---- prologue: r = gamma - S lambda ; r~ = Pinv r ; p = r~ ; eta = r.r~   (pcg.cuh:118-149)
         for (uint32_t i = tid; i < n; i += THREADS) {
             xa[i] = T(0); xa[n + len + i] = T(0);
             xb[i] = T(0); xb[n + len + i] = T(0);
@@ -107,66 +106,64 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
             const T l = lambda[i];
             xa[n + i] = l;
             lam[i] = l;
-            xb[n + i] = T(0);
         }
         __syncthreads();
-        (void)wg_spmv_dot<T, NCT, V, WAVES>(S, xa, yc, xb, m, n, N, lane, wave);
-        __syncthreads();
-        for (uint32_t i = tid; i < len; i += THREADS) xb[n + i] = gamma[i] - yc[i];
-        __syncthreads();
 
-        T eta;
-        {
-            T part = T(0);
-            if (P) {
-                part = wg_spmv_dot<T, NCT, V, WAVES>(P, xb, yc, xb, m, n, N, lane, wave);
-            } else {
-                for (uint32_t i = tid; i < len; i += THREADS) {
-                    const T rv = xb[n + i];
-                    yc[i] = rv;
-                    part = __builtin_fma(rv, rv, part);
-                }
-            }
-            eta = wg_sum<T, WAVES>(part, red1, lane, wave);
-        }
-        for (uint32_t i = tid; i < len; i += THREADS) xa[n + i] = yc[i];
-        __syncthreads();
-
-        // ---- main loop   (pcg.cuh:154-208)
+        // The solve is a sequence of matrix phases with ONE streaming call site:
+        //   phase 0        : yc = S lambda            -> r = gamma - yc                (pcg.cuh:118-126)
+        //   phase 1        : yc = Pinv r, eta = r.yc  -> p = yc                        (pcg.cuh:130-149)
+        //   phase 2+2i     : yc = S p,    v = p.yc    -> alpha; lambda += alpha p; r -= alpha yc   (:156-176)
+        //   phase 3+2i     : yc = Pinv r, eta' = r.yc -> exit test; beta; p = yc + beta p          (:180-206)
         uint32_t iter = 0;
         bool max_iter_exit = true;
-        for (; iter < a.max_iter; ++iter) {
-            // upsilon = S p ; v = p.upsilon ; alpha = eta / v
-            T part = wg_spmv_dot<T, NCT, V, WAVES>(S, xa, yc, xa, m, n, N, lane, wave);
-            const T alpha = eta / wg_sum<T, WAVES>(part, red0, lane, wave);
-            // lambda += alpha p ; r -= alpha upsilon
-            for (uint32_t i = tid; i < len; i += THREADS) {
-                lam[i] = __builtin_fma(alpha, xa[n + i], lam[i]);
-                xb[n + i] = __builtin_fma(-alpha, yc[i], xb[n + i]);
-            }
-            __syncthreads();
-            // r~ = Pinv r ; eta_new = r.r~
-            if (P) {
-                part = wg_spmv_dot<T, NCT, V, WAVES>(P, xb, yc, xb, m, n, N, lane, wave);
-            } else {
-                part = T(0);
+        T eta = T(0);
+        for (uint32_t phase = 0;; ++phase) {
+            const bool precond = phase & 1u;
+            const T *M = precond ? P : S;
+            const T *X = precond ? xb : xa;
+            T part = T(0);
+            if (M) {
+                part = wg_spmv_dot<T, NCT, V, WAVES>(M, X, yc, X, m, n, N, lane, wave);
+            } else {  // identity preconditioner: r~ = r
                 for (uint32_t i = tid; i < len; i += THREADS) {
                     const T rv = xb[n + i];
                     yc[i] = rv;
-                    part = __builtin_fma(rv, rv, part);
+                    part = fma_t(rv, rv, part);
                 }
             }
-            const T eta_new = wg_sum<T, WAVES>(part, red1, lane, wave);
-            if (fabs(eta_new) < a.tol) {  // pcg.cuh:195 (absolute test on r.Pinv r)
+            if (phase == 0) {
+                __syncthreads();
+                for (uint32_t i = tid; i < len; i += THREADS) xb[n + i] = gamma[i] - yc[i];
+                __syncthreads();
+                continue;
+            }
+            const T tot = wg_sum<T, WAVES>(part, precond ? red1 : red0, lane, wave);
+            if (!precond) {
+                const T alpha = eta / tot;
+                for (uint32_t i = tid; i < len; i += THREADS) {
+                    lam[i] = fma_t(alpha, xa[n + i], lam[i]);
+                    xb[n + i] = fma_t(-alpha, yc[i], xb[n + i]);
+                }
+                __syncthreads();
+                continue;
+            }
+            if (phase == 1) {
+                eta = tot;
+                for (uint32_t i = tid; i < len; i += THREADS) xa[n + i] = yc[i];
+                __syncthreads();
+                if (a.max_iter == 0) break;
+                continue;
+            }
+            if (fabs(tot) < a.tol) {  // pcg.cuh:195 (absolute test on r.Pinv r)
                 ++iter;
                 max_iter_exit = false;
                 break;
             }
-            const T beta = eta_new / eta;
-            eta = eta_new;
-            // p = r~ + beta p
-            for (uint32_t i = tid; i < len; i += THREADS) xa[n + i] = __builtin_fma(beta, xa[n + i], yc[i]);
+            const T beta = tot / eta;
+            eta = tot;
+            for (uint32_t i = tid; i < len; i += THREADS) xa[n + i] = fma_t(beta, xa[n + i], yc[i]);
             __syncthreads();
+            if (++iter >= a.max_iter) break;
         }
 
         // ---- outputs   (pcg.cuh:212,215; d_r / d_p as left by :175,:205)
@@ -211,6 +208,11 @@ static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hip
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu == 0) per_cu = 1;
     uint32_t grid = (uint32_t)dev.num_cus * per_cu;
+    static const int grid_cap = [] {
+        const char *e = getenv("GBDPCG_FUSED_GRID");  // tuning runs only
+        return e ? atoi(e) : 0;
+    }();
+    if (grid_cap > 0 && grid > (uint32_t)grid_cap) grid = (uint32_t)grid_cap;
     if (grid > a.batch) grid = a.batch;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
     return hipGetLastError();
@@ -219,9 +221,24 @@ static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hip
 template <typename T, int NCT, int V>
 static hipError_t launch_fused_v(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
 {
-    // few problems: give each the widest workgroup; many problems: 4-wave workgroups, several per CU
-    if (a.batch < (uint32_t)dev.num_cus) return launch_fused_w<T, NCT, V, 16>(dev, a, s);
-    return launch_fused_w<T, NCT, V, 4>(dev, a, s);
+    // Few problems: give each the widest workgroup.  Many problems: 8-wave workgroups, two resident per
+    // CU -- one streams while the other sits in its reduction / vector-update barriers, and only
+    // 2 x CUs problems are in flight at once, which keeps their S + Pinv (re-read every iteration)
+    // largely inside the 256 MiB Infinity Cache (measured on n=14, N=128, batch 1024: 4-wave
+    // workgroups x 4 per CU 6.6 TB/s algorithmic, 8-wave x 2 per CU 7.7 TB/s; profiles/).
+    // GBDPCG_FUSED_WAVES (4, 8 or 16) overrides the choice for tuning runs.
+    static const int forced = [] {
+        const char *e = getenv("GBDPCG_FUSED_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    int waves = a.batch < (uint32_t)dev.num_cus ? 16 : 8;
+    if (forced == 4 || forced == 8 || forced == 16) waves = forced;
+    while (waves > 4 && fused_lds_bytes<T>(a.n, a.N, waves) > dev.lds_per_wg_max) waves /= 2;
+    switch (waves) {
+    case 16: return launch_fused_w<T, NCT, V, 16>(dev, a, s);
+    case 8: return launch_fused_w<T, NCT, V, 8>(dev, a, s);
+    default: return launch_fused_w<T, NCT, V, 4>(dev, a, s);
+    }
 }
 
 template <typename T, int NCT>

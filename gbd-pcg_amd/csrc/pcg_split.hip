@@ -113,7 +113,8 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
     const PcgArgs<T> &a = sa.a;
     const uint32_t n = NCT ? (uint32_t)NCT : a.n;
     const uint32_t N = a.N, len = n * N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps row bases in SGPRs
     const uint32_t prob = blockIdx.x / sa.chunks;
     const uint32_t chunk = blockIdx.x - prob * sa.chunks;
     const uint32_t k0 = chunk * sa.rpw, k1 = min(N, k0 + sa.rpw);
@@ -166,10 +167,10 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                 const int64_t gi = g0 + i;
                 T rv = T(0);
                 if (gi >= 0 && gi < (int64_t)len) {
-                    rv = __builtin_fma(-alpha, ups[gi], r_old[gi]);
+                    rv = fma_t(-alpha, ups[gi], r_old[gi]);
                     if (i >= own_lo && i < own_hi) {
                         rbuf[par][gi] = rv;
-                        lambda[gi] = __builtin_fma(alpha, p_cur[gi], lambda[gi]);
+                        lambda[gi] = fma_t(alpha, p_cur[gi], lambda[gi]);
                     }
                 }
                 win[i] = rv;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                 const int64_t gi = g0 + i;
                 T pn = T(0);
                 if (gi >= 0 && gi < (int64_t)len) {
-                    pn = __builtin_fma(beta, p_old[gi], rt[gi]);
+                    pn = fma_t(beta, p_old[gi], rt[gi]);
                     if (i >= own_lo && i < own_hi) pbuf[par][gi] = pn;
                 }
                 win[i] = pn;
@@ -223,13 +224,10 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
         for (uint32_t i = own_lo + tid; i < own_hi; i += THREADS) {
             const T rv = win[i];
             out[g0 + i] = rv;
-            part = __builtin_fma(rv, rv, part);
+            part = fma_t(rv, rv, part);
         }
     } else {
-        for (uint32_t k = k0 + wave; k < k1; k += WAVES) {
-            T acc[V];
-            block_row_mv<T, NCT, V>(M + (size_t)k * 3 * n * n, win + (k - k0) * n, m, lane,
-                                    k == 0 ? n : 0u, k == N - 1 ? 2 * n : 3 * n, acc);
+        stream_rows<T, NCT, V, StreamGeom<T, NCT, V>::DEPTH>(M, win, k0, k0 + wave, k1, WAVES, N, m, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
             if (m.active && m.g == 0) {
                 const uint32_t row = k * n + m.rp * V;
 #pragma unroll
@@ -238,11 +236,11 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                         rbuf[1][row + v] = a.gamma[(size_t)prob * len + row + v] - acc[v];
                     } else {
                         out[row + v] = acc[v];
-                        part = __builtin_fma(acc[v], win[n + (row - k0 * n) + v], part);
+                        part = fma_t(acc[v], win[n + (row - k0 * n) + v], part);
                     }
                 }
             }
-        }
+        });
     }
     if (PHASE == PH_PRECOND) store_partial<T, WAVES>(part, &pe[par][chunk], red, lane, wave);
     if (PHASE == PH_DIRECTION) store_partial<T, WAVES>(part, &pv[chunk], red, lane, wave);
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(256) void pcg_split_finish(SplitArgs<T> sa)
     const T *rt = ws + w.rt;
     for (uint32_t i = tid; i < len; i += 256) {
         if (a.r) a.r[(size_t)prob * len + i] = r_fin[i];
-        if (a.p) a.p[(size_t)prob * len + i] = update_p ? __builtin_fma(beta, p_last[i], rt[i]) : p_last[i];
+        if (a.p) a.p[(size_t)prob * len + i] = update_p ? fma_t(beta, p_last[i], rt[i]) : p_last[i];
     }
 }
 

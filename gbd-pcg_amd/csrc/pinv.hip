@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_kernel(uint32_t n, uin
                 const uint32_t r = i / w, c = i - r * w;
                 const T pr = tab[j * w + c] * piv;  // scaled pivot-row entry
                 if (r == j) continue;
-                tab[r * w + c] = __builtin_fma(-colj[r], pr, tab[r * w + c]);
+                tab[r * w + c] = fma_t(-colj[r], pr, tab[r * w + c]);
             }
             __syncthreads();
             for (uint32_t c = tid; c < w; c += kPinvThreads) tab[j * w + c] *= piv;
@@ -90,14 +90,14 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, ui
         for (uint32_t i = tid; i < nn; i += kPinvThreads) {
             const uint32_t c = i / n, r = i - c * n;
             T acc = T(0);
-            for (uint32_t q = 0; q < n; ++q) acc = __builtin_fma(A[q * n + r], B[c * n + q], acc);
+            for (uint32_t q = 0; q < n; ++q) acc = fma_t(A[q * n + r], B[c * n + q], acc);
             W[i] = acc;
         }
         __syncthreads();
         for (uint32_t i = tid; i < nn; i += kPinvThreads) {
             const uint32_t c = i / n, r = i - c * n;
             T acc = T(0);
-            for (uint32_t q = 0; q < n; ++q) acc = __builtin_fma(W[q * n + r], C[c * n + q], acc);
+            for (uint32_t q = 0; q < n; ++q) acc = fma_t(W[q * n + r], C[c * n + q], acc);
             Pinv[blk + (side == 0 ? 0 : 2 * (size_t)nn) + i] = -acc;
         }
         __syncthreads();

@@ -3,7 +3,7 @@
 // Replaces loadbdVec + bdmv (/root/reference/include/utils.cuh:9-85) as a standalone operator.
 // Work decomposition: a workgroup owns `rpw` consecutive block-rows of one problem; it stages the
 // (rpw+2)*n halo window of x in LDS once, then each of its wavefronts streams whole block-rows
-// from HBM with block_row_mv (bt_device.hpp).  Algorithmic bytes per problem:
+// from HBM with stream_rows (bt_device.hpp).  Algorithmic bytes per problem:
 // ((3N-2) n^2 + 2 n N) sizeof(T)  (SURVEY.md section 8d).
 #include "bt_device.hpp"
 #include "internal.hpp"
@@ -18,7 +18,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_
 
     const uint32_t n = NCT ? (uint32_t)NCT : a.n;
     const uint32_t N = a.N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps row bases in SGPRs
     const uint32_t prob = blockIdx.x / chunks;
     const uint32_t chunk_id = blockIdx.x - prob * chunks;
     const uint32_t k0 = chunk_id * rpw;
@@ -38,15 +39,18 @@ __global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_
     const LaneMap<NCT, V> m(n, lane);
     const T *M = a.M + (size_t)prob * 3 * n * n * N;
     T *y = a.y + (size_t)prob * len;
-    for (uint32_t k = k0 + wave; k < k1; k += WAVES) {
-        T acc[V];
-        block_row_mv<T, NCT, V>(M + (size_t)k * 3 * n * n, xs + (k - k0) * n, m, lane,
-                                k == 0 ? n : 0u, k == N - 1 ? 2 * n : 3 * n, acc);
+    // y of this chunk is collected in LDS (no global stores inside the streaming loop) and written
+    // out as one dense run at the end
+    T *ys = xs + align16<T>((rpw + 2) * n);
+    stream_rows<T, NCT, V, StreamGeom<T, NCT, V>::DEPTH>(M, xs, k0, k0 + wave, k1, WAVES, N, m, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
         if (m.active && m.g == 0) {
 #pragma unroll
-            for (int v = 0; v < V; ++v) y[(size_t)k * n + m.rp * V + v] = acc[v];
+            for (int v = 0; v < V; ++v) ys[(k - k0) * n + m.rp * V + v] = acc[v];
         }
-    }
+    });
+    __syncthreads();
+    const uint32_t ycnt = (k1 - k0) * n;
+    for (uint32_t i = tid; i < ycnt; i += WAVES * 64) y[(size_t)k0 * n + i] = ys[i];
 }
 
 template <typename T, int NCT, int V>
@@ -61,7 +65,7 @@ static hipError_t launch_spmv_v(const DeviceInfo &dev, const SpmvArgs<T> &a, hip
     if (rpw > a.N) rpw = a.N;
     if (rpw == 0) rpw = 1;
     const uint32_t chunks = (a.N + rpw - 1) / rpw;
-    const size_t lds = (size_t)(rpw + 2) * a.n * sizeof(T);
+    const size_t lds = ((size_t)align16<T>((rpw + 2) * a.n) + align16<T>(rpw * a.n)) * sizeof(T);
     if (lds > dev.lds_per_wg_max) return hipErrorInvalidValue;
     auto kern = spmv_kernel<T, NCT, V, WAVES>;
     if (lds > 64 * 1024) {

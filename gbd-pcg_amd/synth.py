@@ -18,8 +18,9 @@ Two generators with the same math:
   * gen_numpy : canonical, reproducible anywhere (own counter-based RNG, no
                 dependence on numpy's or torch's generator streams); used by the
                 parity tests and the golden fixtures.
-  * gen_torch : same construction with torch ops on the GPU (torch RNG), for
-                bench-sized batches where only the shape/conditioning matters.
+  * gen_torch : same construction with torch ops on the GPU (torch RNG; Q_k from Householder
+                products instead of QR), for bench-sized batches where only the
+                shape/conditioning matters.
 """
 from __future__ import annotations
 
@@ -141,13 +142,16 @@ def gen_torch(n: int, N: int, batch: int, device, dtype, seed: int = 1234, a: fl
 
     for lo in range(0, batch, chunk):
         b = min(chunk, batch - lo)
-        A = torch.randn((b, N - 1, n, n), generator=g, device=device, dtype=torch.float64)
+        # Q_k: product of n Householder reflections of random vectors -- exactly orthogonal and pure
+        # elementwise/bmm work (torch.linalg.qr on the GPU launches several kernels per matrix)
+        Vh = torch.randn((b, N - 1, n, n), generator=g, device=device, dtype=torch.float64)
         Mk = torch.randn((b, N, n, n), generator=g, device=device, dtype=torch.float64) / n ** 0.5
         gam = torch.randn((b, N * n), generator=g, device=device, dtype=torch.float64)
-        Q, Rq = torch.linalg.qr(A)
-        sg = torch.sign(torch.diagonal(Rq, dim1=-2, dim2=-1))
-        sg = torch.where(sg == 0, torch.ones_like(sg), sg)
-        Q = Q * sg.unsqueeze(-2)
+        Q = eye.expand(b, N - 1, n, n).clone()
+        for j in range(n):
+            v = Vh[..., j]
+            v = v / v.norm(dim=-1, keepdim=True)
+            Q = Q - 2.0 * (Q @ v.unsqueeze(-1)) * v.unsqueeze(-2)
         W = eye + Mk @ Mk.transpose(-1, -2)
         D = W.clone()
         L = torch.zeros_like(W)
