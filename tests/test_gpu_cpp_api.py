@@ -1,0 +1,70 @@
+"""The C++ drop-in surface (include/gbdpcg.hpp: solvePCG<T> x3, pcg_solve<T>, pcg_config<T>, csr_t<T>,
+pcgSharedMemSize<T>, checkPcgOccupancy<T>) driven from compiled host code, the way MPCGPU would
+call it, checked against the CPU oracle on the reference's example system."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gbd_pcg_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "gbd-pcg_amd", "examples")
+
+
+def run(name):
+    exe = os.path.join(EX, name)
+    assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() makes it"
+    return subprocess.run([exe], capture_output=True, text=True, timeout=120, check=True).stdout
+
+
+def parse(out):
+    rec = {}
+    for line in out.splitlines():
+        if " iters=" in line:
+            tag, rest = line.split(" iters=")
+            it, lam = rest.split(" lambda=")
+            rec[tag] = (int(it), np.array([float(v) for v in lam.split()]))
+    return rec
+
+
+def test_selftest_against_oracle(orc):
+    out = run("api_selftest")
+    rec = parse(out)
+    n, N, S, gamma = orc.readme_system()
+    lam_star = np.linalg.solve(orc.dense_from_bt(n, N, S), gamma)
+    L, D, R = synth.unpack_bt(n, N, S)
+    P = synth.pack_bt(*synth.stair_pinv_blocks(L, D, R))
+    assert "f64 smem=400 occupancy=1" in out and "f32 smem=200 occupancy=1" in out   # pcg.cuh:13-20
+
+    o_id = orc.pcg(n, N, S, None, gamma, tol=1e-6, max_iter=25)
+    o_st = orc.pcg(n, N, S, P, gamma, tol=1e-6, max_iter=25)
+    for tag in ("host_ident", "pcg_solve", "device_ident", "csr_ident"):
+        it, lam = rec[f"f64 {tag}"]
+        assert it == o_id["iters"] == 6
+        assert np.linalg.norm(lam - o_id["lambda_"]) / np.linalg.norm(o_id["lambda_"]) < 1e-10
+        assert np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 1e-10
+    it, lam = rec["f64 host_stair"]
+    assert it == o_st["iters"] == 3 and np.linalg.norm(lam - o_st["lambda_"]) / np.linalg.norm(lam_star) < 1e-10
+    it, res = rec["f64 device_resid"]
+    assert np.linalg.norm(res - o_id["r"]) < 1e-9 * np.linalg.norm(gamma)
+
+    # fp32: kappa ~ 1562, answers agree to ~1e-5; iteration count with Pinv = I is order-sensitive
+    for tag in ("host_ident", "pcg_solve", "device_ident", "csr_ident"):
+        it, lam = rec[f"f32 {tag}"]
+        assert it in (8, 9) and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 2e-4
+    it, lam = rec["f32 host_stair"]
+    assert it == 3 and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 5e-5
+
+
+@pytest.mark.parametrize("exe", ["pcg_solve", "pcg_solve_dp"])
+def test_example_drivers_print_like_the_reference(exe):
+    """examples/pcg_solve.cu:36-41 prints 'GBD-PCG returned in <res> iters.' then 'Lambda: ' and six values."""
+    out = run(exe).splitlines()
+    assert out[0].startswith("GBD-PCG returned in ") and out[0].endswith(" iters.")
+    assert out[1].strip() == "Lambda:"
+    lam = np.array([float(v) for v in out[2].split()])
+    want = np.array([-303.702986086, -46.415939681, -315.176302632, -14.898309418, -298.790861920, 13.503782688])
+    assert lam.shape == (6,) and np.linalg.norm(lam - want) / np.linalg.norm(want) < (2e-4 if exe == "pcg_solve" else 1e-5)
