@@ -73,7 +73,7 @@ template <typename T> static void run(const char *prec)
         gpuErrchk(hipMemcpy(r, d_r, sizeof r, hipMemcpyDeviceToHost));
         snprintf(tag, sizeof tag, "%s device_resid", prec);
         report(tag, it, r);
-        hipFree(d_S); hipFree(d_P); hipFree(d_g); hipFree(d_l); hipFree(d_r); hipFree(d_p); hipFree(d_v); hipFree(d_e);
+        for (T *q : {d_S, d_P, d_g, d_l, d_r, d_p, d_v, d_e}) gpuErrchk(hipFree(q));
     }
     {   // CSR overload: dense-ish CSR of the same matrix (zeros of the pattern included)
         std::vector<uint32_t> row_ptr(1, 0), col;

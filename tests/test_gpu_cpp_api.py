@@ -55,8 +55,8 @@ def test_selftest_against_oracle(orc):
     for tag in ("host_ident", "pcg_solve", "device_ident", "csr_ident"):
         it, lam = rec[f"f32 {tag}"]
         assert it in (8, 9) and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 2e-4
-    it, lam = rec["f32 host_stair"]
-    assert it == 3 and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 5e-5
+    it, lam = rec["f32 host_stair"]   # Pinv formed in fp32 on the device: 3 or 4
+    assert it in (3, 4) and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 5e-5
 
 
 @pytest.mark.parametrize("exe", ["pcg_solve", "pcg_solve_dp"])
