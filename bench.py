@@ -92,7 +92,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gbd_pcg_amd import binding, synth
+    from gbd_pcg_amd import binding, sharding, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -138,10 +138,8 @@ def main():
         step(events[k])
     fence()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # RCCL over xGMI: throughput aggregation only
-        elapsed = float(t.item())
+    # RCCL over xGMI: throughput aggregation only (max elapsed, total problem-iterations)
+    elapsed, total_units = sharding.aggregate(elapsed, float(B * iters * args.steps), device="cuda")
     assert int(it_out.min()) == iters and int(it_out.max()) == iters
     assert torch.isfinite(lam).all()
 
@@ -173,7 +171,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "PCG iterations/sec (problem-iterations, block-tridiag stateSize x knotPoints = 14 x 128)",
-            "value": world * B * iters * args.steps / elapsed,
+            "value": total_units / elapsed,
             "unit": "iter/s",
             "n_gpus": world,
             "steps": args.steps,

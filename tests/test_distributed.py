@@ -1,0 +1,69 @@
+"""N > 1 host logic on CPU: world_size-2 gloo.  The data path has no collective (independent
+problems); what is distributed is the sharding of the batch and the aggregation of the numbers
+bench.py reports (max elapsed over ranks, total units)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gbd_pcg_amd import sharding
+
+
+def test_shard_range_covers_batch_exactly():
+    for batch in (1, 7, 8, 1024, 8192, 8193):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(batch, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gbd_pcg_amd import synth
+        from oracle import oracle as orc
+        # each rank solves its own shard of an 6-problem batch with the CPU oracle (stand-in for the
+        # GPU solve in this CPU-only test) and the ranks aggregate throughput numbers
+        n, N, B = 14, 8, 6
+        lo, hi = sharding.shard_range(B, rank, world)
+        d = synth.gen_numpy(n, N, seed=1234 + lo, batch=hi - lo, dtype=np.float64)
+        ob = orc.pcg_batch(n, N, hi - lo, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=50)
+        units = float(ob["iters"].sum())
+        elapsed, total = sharding.aggregate(1.0 + rank, units)
+        dist.barrier()
+        if rank == 0:
+            full = synth.gen_numpy(n, N, seed=1234, batch=B, dtype=np.float64)
+            of = orc.pcg_batch(n, N, B, full["S"], full["Pinv"], full["gamma"], tol=1e-6, max_iter=50)
+            out.put((elapsed, total, float(of["iters"].sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_aggregation():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    elapsed, total, want = out.get(timeout=5)
+    assert elapsed == 2.0          # max over ranks
+    assert total == want           # shards together did exactly the work of the whole batch
