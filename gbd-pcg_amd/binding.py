@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgbdpcg.so")
+# GBDPCG_LIB: alternative build of the same library (A/B tuning runs on one device)
+LIB_PATH = os.environ.get("GBDPCG_LIB") or os.path.join(CSRC, "libgbdpcg.so")
 
 OK = 0
 PATH_AUTO, PATH_FUSED, PATH_SPLIT = 0, 1, 2

@@ -211,101 +211,112 @@ __device__ __forceinline__ void block_row_mv_rt(const T *__restrict__ Mk, const 
     }
 }
 
-// Stream the block-rows k = k_begin, k_begin + k_step, ... < k_end of one problem through this
-// wavefront.  M is the problem's matrix base; row k multiplies the LDS window xw + (k - k_x0)*n
-// (xw[c] for column c of row k_x0, zero-padded by the caller where the vector ends).
-// on_row(k, acc) is called by every lane after each row; lanes with g == 0 && active hold
-// y_k[rp*V + v] in acc[v].
+// RowStream: stream the block-rows k = k_begin, k_begin + k_step, ... < k_end of one problem
+// through this wavefront, in two calls so that the first matrix loads are already in flight while
+// the caller still prepares the x operand (LDS staging, reductions, barriers):
 //
-// NCT > 0: the wave's rows are cut into units (StreamGeom) numbered q = 0, 1, ...; a ring of
-// DEPTH register-resident units keeps DEPTH-1 units of loads in flight behind the one being
-// multiplied (loads return in order, so the compiler's counted vmcnt waits only for the oldest).
-// The ring slot is a compile-time index (the loop is unrolled by DEPTH); row and unit-in-row
-// are runtime values that only enter address arithmetic.
-template <typename T, int NCT, int V, int DEPTH, typename RowFn>
-__device__ __forceinline__ void stream_rows(const T *__restrict__ M, const T *xw, uint32_t k_x0, uint32_t k_begin,
-                                            uint32_t k_end, uint32_t k_step, uint32_t N, const LaneMap<NCT, V> &m,
-                                            uint32_t lane, RowFn &&on_row)
-{
-    const uint32_t n = m.n;
-    const size_t row_elems = (size_t)3 * n * n;
-    if constexpr (NCT > 0) {
-        using Gm = StreamGeom<T, NCT, V>;
-        StreamUnit<T, NCT, V> ring[DEPTH];
-        const StreamCtx<T, NCT, V> cx(m, lane);
+//   prime(M, k_begin, k_end, k_step)   issue the first DEPTH units into the register ring.
+//                                      Branch-free: exactly DEPTH*CH loads whatever the row count
+//                                      (slots past the last unit re-read row 0, always in bounds).
+//   run(xw, k_x0, N, on_row)           multiply; row k uses the LDS window xw + (k - k_x0)*n
+//                                      (xw[c] = column c of row k_x0, zero-padded by the caller
+//                                      where the vector ends).  on_row(k, acc) is called by every
+//                                      lane after each row; lanes with g == 0 && active hold
+//                                      y_k[rp*V + v] in acc[v].
+//
+// NCT > 0: the wave's rows are cut into units (StreamGeom) numbered q = 0, 1, ...; the ring keeps
+// DEPTH-1 units of loads in flight behind the one being multiplied.  Loads return in order, the
+// ring is always primed with the same number of loads and the steady-state loop refills every slot
+// it consumes with no data-dependent control flow, so hipcc's counted vmcnt waits see exactly
+// DEPTH-1 younger units (a conditionally primed ring makes its waitcnt pass assume the shortest
+// queue and drain every iteration).  The ring slot is a compile-time index (loops unrolled by
+// DEPTH); row and unit-in-row are runtime values that only enter address arithmetic.
+// NCT == 0 (runtime n): prime() does nothing and run() is a plain loop over rows.
+template <typename T, int NCT, int V> struct RowStream {
+    using Gm = StreamGeom<T, NCT, V>;
+    static constexpr int DEPTH = Gm::DEPTH;
+    StreamUnit<T, NCT, V> ring[DEPTH];
+    const T *M;
+    uint32_t k_begin, k_end, k_step, total;
+
+    __device__ __forceinline__ void issue(uint32_t q, int slot, const StreamCtx<T, NCT, V> &cx, uint32_t n) {
+        const uint32_t ri = q / Gm::UPR, u = q - ri * Gm::UPR;
+        const uint32_t k = q < total ? k_begin + ri * k_step : 0u;
+        load_unit<T, NCT, V>(M + (size_t)k * 3 * n * n, u, cx, ring[slot]);
+    }
+
+    __device__ __forceinline__ void prime(const T *__restrict__ M_, uint32_t k_begin_, uint32_t k_end_,
+                                          uint32_t k_step_, const StreamCtx<T, NCT, V> &cx, uint32_t n) {
+        M = M_;
+        k_begin = k_begin_;
+        k_end = k_end_;
+        k_step = k_step_;
         const uint32_t nrows = k_end > k_begin ? (k_end - k_begin + k_step - 1) / k_step : 0;
-        const uint32_t total = nrows * Gm::UPR;
-        // (kept as a macro-like inline block: a by-reference lambda here would not be inlined at
-        // every call site and the ring would fall out of registers into scratch)
-#define GBDPCG_ISSUE(q_, slot_)                                                                         \
-    do {                                                                                                \
-        const uint32_t ri_ = (q_) / Gm::UPR, u_ = (q_) - ri_ * Gm::UPR;                                 \
-        load_unit<T, NCT, V>(M + (k_begin + ri_ * k_step) * row_elems, u_, cx, (slot_));                \
-    } while (0)
-        T acc[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) acc[v] = T(0);
-        // multiply unit q out of ring slot j_, optionally refill the slot with unit q + DEPTH
-#define GBDPCG_CONSUME(q_, j_, refill_)                                                                 \
-    do {                                                                                                \
-        const uint32_t ri = (q_) / Gm::UPR, u = (q_) - ri * Gm::UPR;                                    \
-        const uint32_t k = k_begin + ri * k_step;                                                       \
-        const T *xk = xw + (k - k_x0) * n;                                                              \
-        if (k == 0 || k == N - 1) { /* wave-uniform */                                                  \
-            fma_unit<T, NCT, V, true>(ring[j_], u, xk, cx, m.g, k == 0 ? n : 0u,                        \
-                                      k == N - 1 ? 2 * n : 3 * n, acc);                                 \
-        } else {                                                                                        \
-            fma_unit<T, NCT, V, false>(ring[j_], u, xk, cx, m.g, 0u, 3 * n, acc);                       \
-        }                                                                                               \
-        if (refill_) GBDPCG_ISSUE((q_) + DEPTH, ring[j_]);                                              \
-        if (Gm::UPR == 1 || u == Gm::UPR - 1) {                                                         \
-            fold_groups<T, NCT, V>(m, acc);                                                             \
-            on_row(k, acc);                                                                             \
-            _Pragma("unroll") for (int v = 0; v < V; ++v) acc[v] = T(0);                                \
-        }                                                                                               \
-    } while (0)
-        // Steady state: the ring is primed unconditionally and every consumed slot is refilled, with
-        // no data-dependent control flow around the loads, so the compiler's counted vmcnt waits see
-        // exactly DEPTH-1 younger units in flight.  (A conditionally primed ring would make the
-        // waitcnt pass assume the shortest queue at the loop header and drain it every iteration.)
-        uint32_t q0 = 0;
-        if (total >= 2 * DEPTH) {
+        total = nrows * Gm::UPR;
+        if constexpr (NCT > 0) {
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
-                GBDPCG_ISSUE((uint32_t)j, ring[j]);
-                // keep the units' loads in issue order: the loop's counted waits assume it
-                __builtin_amdgcn_sched_barrier(0);
+                issue((uint32_t)j, j, cx, n);
+                __builtin_amdgcn_sched_barrier(0);  // keep units in issue order: the waits count on it
             }
-            do {
-#pragma unroll
-                for (int j = 0; j < DEPTH; ++j) GBDPCG_CONSUME(q0 + j, j, true);
-                q0 += DEPTH;
-            } while (q0 + 2 * DEPTH <= total);
-        } else {
-#pragma unroll
-            for (int j = 0; j < DEPTH; ++j)
-                if ((uint32_t)j < total) GBDPCG_ISSUE((uint32_t)j, ring[j]);
-        }
-        // drain: at most 2*DEPTH-1 units left
-        for (; q0 < total; q0 += DEPTH) {
-#pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
-                const uint32_t q = q0 + j;
-                if (q < total) GBDPCG_CONSUME(q, j, q + DEPTH < total);
-            }
-        }
-#undef GBDPCG_CONSUME
-#undef GBDPCG_ISSUE
-    } else {
-        for (uint32_t k = k_begin; k < k_end; k += k_step) {
-            T acc[V];
-            block_row_mv_rt<T, V>(M + k * row_elems, xw + (k - k_x0) * n, m, lane, k == 0 ? n : 0u,
-                                  k == N - 1 ? 2 * n : 3 * n, acc);
-            fold_groups<T, NCT, V>(m, acc);
-            on_row(k, acc);
         }
     }
-}
+
+    template <bool REFILL, typename RowFn>
+    __device__ __forceinline__ void consume(uint32_t q, int slot, const T *xw, uint32_t k_x0, uint32_t N,
+                                            const LaneMap<NCT, V> &m, const StreamCtx<T, NCT, V> &cx, bool refill,
+                                            T (&acc)[V], RowFn &&on_row) {
+        const uint32_t n = m.n;
+        const uint32_t ri = q / Gm::UPR, u = q - ri * Gm::UPR;
+        const uint32_t k = k_begin + ri * k_step;
+        const T *xk = xw + (k - k_x0) * n;
+        if (k == 0 || k == N - 1) {  // wave-uniform
+            fma_unit<T, NCT, V, true>(ring[slot], u, xk, cx, m.g, k == 0 ? n : 0u, k == N - 1 ? 2 * n : 3 * n, acc);
+        } else {
+            fma_unit<T, NCT, V, false>(ring[slot], u, xk, cx, m.g, 0u, 3 * n, acc);
+        }
+        if (REFILL || refill) issue(q + DEPTH, slot, cx, n);
+        if (Gm::UPR == 1 || u == Gm::UPR - 1) {
+            fold_groups<T, NCT, V>(m, acc);
+            on_row(k, acc);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = T(0);
+        }
+    }
+
+    template <typename RowFn>
+    __device__ __forceinline__ void run(const T *xw, uint32_t k_x0, uint32_t N, const LaneMap<NCT, V> &m,
+                                        const StreamCtx<T, NCT, V> &cx, uint32_t lane, RowFn &&on_row) {
+        if constexpr (NCT > 0) {
+            T acc[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = T(0);
+            uint32_t q0 = 0;
+            // steady state: every consumed slot is refilled
+            for (; q0 + 2 * DEPTH <= total; q0 += DEPTH) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) consume<true>(q0 + j, j, xw, k_x0, N, m, cx, true, acc, on_row);
+            }
+            // drain: at most 2*DEPTH-1 units left
+            for (; q0 < total; q0 += DEPTH) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) {
+                    const uint32_t q = q0 + j;
+                    if (q < total) consume<false>(q, j, xw, k_x0, N, m, cx, q + DEPTH < total, acc, on_row);
+                }
+            }
+        } else {
+            const uint32_t n = m.n;
+            for (uint32_t k = k_begin; k < k_end; k += k_step) {
+                T acc[V];
+                block_row_mv_rt<T, V>(M + (size_t)k * 3 * n * n, xw + (k - k_x0) * n, m, lane, k == 0 ? n : 0u,
+                                      k == N - 1 ? 2 * n : 3 * n, acc);
+                fold_groups<T, NCT, V>(m, acc);
+                on_row(k, acc);
+            }
+        }
+    }
+};
 
 // All-lanes sum of one value per lane (butterfly; every lane returns the total).
 template <typename T> __device__ __forceinline__ T wave_sum(T v)

@@ -39,15 +39,15 @@ template <typename T> struct FusedCarve {
     }
 };
 
-// y = M * X (X padded in LDS) for the block-rows of this wave; returns this LANE's partial of
-// dot(y, D) where D is a padded LDS vector (D + n is its first element).
-template <typename T, int NCT, int V, int WAVES>
-__device__ __forceinline__ T wg_spmv_dot(const T *__restrict__ M, const T *X, T *Y, const T *D,
-                                         const LaneMap<NCT, V> &m, uint32_t n, uint32_t N,
-                                         uint32_t lane, uint32_t wave)
+// y = M * X (X padded in LDS) for the block-rows of this wave, out of an already primed stream;
+// returns this LANE's partial of dot(y, D) where D is a padded LDS vector (D + n = first element).
+template <typename T, int NCT, int V>
+__device__ __forceinline__ T wg_spmv_dot(RowStream<T, NCT, V> &rs, const T *X, T *Y, const T *D,
+                                         const LaneMap<NCT, V> &m, const StreamCtx<T, NCT, V> &cx, uint32_t n,
+                                         uint32_t N, uint32_t lane)
 {
     T part = T(0);
-    stream_rows<T, NCT, V, StreamGeom<T, NCT, V>::DEPTH>(M, X, 0u, wave, N, WAVES, N, m, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
+    rs.run(X, 0u, N, m, cx, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
         if (m.active && m.g == 0) {
             const uint32_t row = k * n + m.rp * V;
 #pragma unroll
@@ -90,6 +90,8 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     T *xa = smem + cv.xa, *xb = smem + cv.xb, *yc = smem + cv.yc, *lam = smem + cv.lam;
     T *red0 = smem + cv.red, *red1 = red0 + WAVES;
     const LaneMap<NCT, V> m(n, lane);
+    const StreamCtx<T, NCT, V> cx(m, lane);
+    RowStream<T, NCT, V> rs;
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
@@ -98,6 +100,8 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
         const T *gamma = a.gamma + (size_t)prob * len;
         T *lambda = a.lambda + (size_t)prob * len;
 
+        // first matrix phase's loads go out before anything else touches memory
+        rs.prime(S, wave, N, WAVES, cx, n);
         for (uint32_t i = tid; i < n; i += THREADS) {
             xa[i] = T(0); xa[n + len + i] = T(0);
             xb[i] = T(0); xb[n + len + i] = T(0);
@@ -114,22 +118,32 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
         //   phase 1        : yc = Pinv r, eta = r.yc  -> p = yc                        (pcg.cuh:130-149)
         //   phase 2+2i     : yc = S p,    v = p.yc    -> alpha; lambda += alpha p; r -= alpha yc   (:156-176)
         //   phase 3+2i     : yc = Pinv r, eta' = r.yc -> exit test; beta; p = yc + beta p          (:180-206)
+        // Each phase primes its own ring at its top.  Priming the NEXT phase's ring before the
+        // reduction / update barriers (-DGBDPCG_EARLY_PRIME) was measured 2.6 % slower on config 3
+        // (A/B on one device, profiles/r01_ab_prime.txt): two workgroups per CU already cover each
+        // other's barrier gaps and the early loads only lengthen the reduction's critical path.
         uint32_t iter = 0;
         bool max_iter_exit = true;
         T eta = T(0);
         for (uint32_t phase = 0;; ++phase) {
             const bool precond = phase & 1u;
-            const T *M = precond ? P : S;
             const T *X = precond ? xb : xa;
+#ifndef GBDPCG_EARLY_PRIME
+            if (phase > 0 && !(precond && !P)) rs.prime(precond ? P : S, wave, N, WAVES, cx, n);
+#endif
             T part = T(0);
-            if (M) {
-                part = wg_spmv_dot<T, NCT, V, WAVES>(M, X, yc, X, m, n, N, lane, wave);
-            } else {  // identity preconditioner: r~ = r
+            if (precond && !P) {  // identity preconditioner: r~ = r (the primed S units stay in flight)
                 for (uint32_t i = tid; i < len; i += THREADS) {
                     const T rv = xb[n + i];
                     yc[i] = rv;
                     part = fma_t(rv, rv, part);
                 }
+            } else {
+                part = wg_spmv_dot<T, NCT, V>(rs, X, yc, X, m, cx, n, N, lane);
+#ifdef GBDPCG_EARLY_PRIME
+                // next phase streams the other matrix (or S again under the identity preconditioner)
+                rs.prime((precond || !P) ? S : P, wave, N, WAVES, cx, n);
+#endif
             }
             if (phase == 0) {
                 __syncthreads();

@@ -61,17 +61,18 @@ template <typename T> struct SplitArgs {
     uint32_t rpw, chunks;
 };
 
-// Sum `count` partials from global memory in ascending order; every thread returns the same bits.
-// `stage` is LDS scratch of >= count elements.  Contains two barriers.
+// Sum `count` partials from global memory; every thread of every workgroup returns the same bits
+// (fixed order: lane l adds elements l, l+64, ... ascending, then the wave butterfly), which is what
+// keeps the exit test uniform across the grid.  `stage` is LDS scratch of >= count elements.
 template <typename T>
 __device__ __forceinline__ T sum_partials(const T *g, uint32_t count, T *stage, uint32_t tid, uint32_t nthreads)
 {
     __syncthreads();
     for (uint32_t i = tid; i < count; i += nthreads) stage[i] = g[i];
     __syncthreads();
-    T tot = stage[0];
-    for (uint32_t i = 1; i < count; ++i) tot += stage[i];
-    return tot;
+    T v = T(0);
+    for (uint32_t i = tid & 63u; i < count; i += 64) v += stage[i];
+    return wave_sum(v);
 }
 
 template <typename T, int WAVES>
@@ -120,6 +121,17 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
     const uint32_t k0 = chunk * sa.rpw, k1 = min(N, k0 + sa.rpw);
 
     if (PHASE != PH_INIT_R && sa.done[prob]) return;
+
+    // matrix loads first: they depend on no vector, so they fly while partials are summed and the
+    // x window is built
+    const LaneMap<NCT, V> m(n, lane);
+    const StreamCtx<T, NCT, V> cx(m, lane);
+    RowStream<T, NCT, V> rs;
+    {
+        const size_t ms = (size_t)3 * n * n * N;
+        const T *M0 = (PHASE == PH_PRECOND) ? (a.Pinv ? a.Pinv + prob * ms : a.S + prob * ms) : a.S + prob * ms;
+        rs.prime(M0, k0 + wave, k1, WAVES, cx, n);
+    }
 
     T *win = reinterpret_cast<T *>(smem_raw);
     T *stage = win + align16<T>((sa.rpw + 2) * n);
@@ -217,7 +229,6 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
     }
     __syncthreads();
 
-    const LaneMap<NCT, V> m(n, lane);
     T part = T(0);
     if (PHASE == PH_PRECOND && M == nullptr) {
         // identity preconditioner: r~ = r
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
             part = fma_t(rv, rv, part);
         }
     } else {
-        stream_rows<T, NCT, V, StreamGeom<T, NCT, V>::DEPTH>(M, win, k0, k0 + wave, k1, WAVES, N, m, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
+        rs.run(win, k0, N, m, cx, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
             if (m.active && m.g == 0) {
                 const uint32_t row = k * n + m.rp * V;
 #pragma unroll
@@ -303,11 +314,14 @@ static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, voi
     size_t vec_bytes = (w.per_problem * sizeof(T) * a.batch + 15) / 16 * 16;
     sa.done = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(workspace) + vec_bytes);
 
-    // ~4 workgroups per CU over all problems, whole block-rows per wave
+    // ~4 workgroups per CU over all problems, whole block-rows per wave, and never fewer rows than
+    // waves in a workgroup (a single large problem then uses fewer, fully busy workgroups and has
+    // fewer partials to sum)
     const uint64_t total_rows = (uint64_t)a.N * a.batch;
     const uint64_t target = (uint64_t)dev.num_cus * 4;
     uint32_t rpw = (uint32_t)((total_rows + target - 1) / target);
-    if (rpw >= (uint32_t)WAVES) rpw = (rpw + WAVES - 1) / WAVES * WAVES;
+    if (rpw < (uint32_t)WAVES) rpw = WAVES;
+    rpw = (rpw + WAVES - 1) / WAVES * WAVES;
     if (rpw > a.N) rpw = a.N;
     if (rpw == 0) rpw = 1;
     while (split_lds_elems<T>(a.n, rpw, (a.N + rpw - 1) / rpw) * sizeof(T) > dev.lds_per_wg_max && rpw > 1) rpw /= 2;

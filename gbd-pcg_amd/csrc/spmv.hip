@@ -26,6 +26,13 @@ __global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_
     const uint32_t k1 = min(N, k0 + rpw);
     const size_t len = (size_t)n * N;
 
+    // matrix loads first: they do not depend on x, so they are in flight while x is staged
+    const LaneMap<NCT, V> m(n, lane);
+    const StreamCtx<T, NCT, V> cx(m, lane);
+    const T *M = a.M + (size_t)prob * 3 * n * n * N;
+    RowStream<T, NCT, V> rs;
+    rs.prime(M, k0 + wave, k1, WAVES, cx, n);
+
     // halo window [x_{k0-1} .. x_{k1}] with zeros outside the vector
     const T *x = a.x + (size_t)prob * len;
     const uint32_t cnt = (k1 - k0 + 2) * n;
@@ -36,13 +43,11 @@ __global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_
     }
     __syncthreads();
 
-    const LaneMap<NCT, V> m(n, lane);
-    const T *M = a.M + (size_t)prob * 3 * n * n * N;
-    T *y = a.y + (size_t)prob * len;
     // y of this chunk is collected in LDS (no global stores inside the streaming loop) and written
     // out as one dense run at the end
+    T *y = a.y + (size_t)prob * len;
     T *ys = xs + align16<T>((rpw + 2) * n);
-    stream_rows<T, NCT, V, StreamGeom<T, NCT, V>::DEPTH>(M, xs, k0, k0 + wave, k1, WAVES, N, m, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
+    rs.run(xs, k0, N, m, cx, lane, [&](uint32_t k, const T(&acc)[V]) __attribute__((always_inline)) {
         if (m.active && m.g == 0) {
 #pragma unroll
             for (int v = 0; v < V; ++v) ys[(k - k0) * n + m.rp * V + v] = acc[v];
