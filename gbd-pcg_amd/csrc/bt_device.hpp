@@ -146,22 +146,23 @@ __device__ __forceinline__ void load_unit(const T *__restrict__ Mk, uint32_t u, 
     }
 }
 
-// acc += unit * x for the row whose x window starts at xk (xk[c] multiplies column c).
+// acc += unit * x.  xg / xl point at this lane's x entries of the row: xg = &x_row[xcol] (then
+// column group s sits G*s further), xl = &x_row[xcol_last] (the ragged last step).  Callers build
+// them as `lane base + row offset` so that rows share address registers.
 // EDGE rows (k = 0 or k = N-1) additionally zero the columns outside [c_lo, c_hi): L_0 / R_{N-1}
 // may hold anything and must not reach the result (pcg.cuh:105-106, utils.cuh:58-75).
 template <typename T, int NCT, int V, bool EDGE>
-__device__ __forceinline__ void fma_unit(const StreamUnit<T, NCT, V> &t, uint32_t u, const T *xk,
+__device__ __forceinline__ void fma_unit(const StreamUnit<T, NCT, V> &t, uint32_t u, const T *xg, const T *xl,
                                          const StreamCtx<T, NCT, V> &cx, uint32_t g, uint32_t c_lo, uint32_t c_hi,
                                          T (&acc)[V])
 {
     using Gm = StreamGeom<T, NCT, V>;
-    const T *xg = xk + cx.xcol;
 #pragma unroll
     for (uint32_t j = 0; j < Gm::CH; ++j) {
         const uint32_t s = u * Gm::CH + j;
         if (Gm::STEPS % Gm::CH == 0 || s < Gm::STEPS) {
             const bool last = StreamCtx<T, NCT, V>::RAGGED && s == Gm::STEPS - 1;
-            const T xv = last ? xk[cx.xcol_last] : xg[Gm::G * s];
+            const T xv = last ? xl[0] : xg[Gm::G * s];
             bool keep = last ? cx.ok_last : true;
             if (EDGE) {
                 const uint32_t c = g + Gm::G * s;
@@ -185,6 +186,28 @@ __device__ __forceinline__ void fold_groups(const LaneMap<NCT, V> &m, T (&acc)[V
             const T other = __shfl_down(acc[v], off * m.rpc, kWave);
             if (m.g < off && m.g + off < size) acc[v] += other;
         }
+        size = off;
+    }
+}
+
+// The same fold for R independent rows at once: each tree level issues all R*V shuffles before any
+// add, so the LDS-crossbar latency of a level is paid once, not R times.
+template <typename T, int NCT, int V, int R>
+__device__ __forceinline__ void fold_groups_multi(const LaneMap<NCT, V> &m, T (&acc)[R][V])
+{
+    uint32_t size = m.G;
+    for (uint32_t off = pow2_ceil(m.G) >> 1; off >= 1; off >>= 1) {
+        T other[R][V];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int v = 0; v < V; ++v) other[i][v] = __shfl_down(acc[i][v], off * m.rpc, kWave);
+        const bool take = m.g < off && m.g + off < size;
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                if (take) acc[i][v] += other[i][v];
         size = off;
     }
 }
@@ -269,11 +292,12 @@ template <typename T, int NCT, int V> struct RowStream {
         const uint32_t n = m.n;
         const uint32_t ri = q / Gm::UPR, u = q - ri * Gm::UPR;
         const uint32_t k = k_begin + ri * k_step;
-        const T *xk = xw + (k - k_x0) * n;
+        const uint32_t roff = (k - k_x0) * n;
+        const T *xg = xw + cx.xcol + roff, *xl = xw + cx.xcol_last + roff;
         if (k == 0 || k == N - 1) {  // wave-uniform
-            fma_unit<T, NCT, V, true>(ring[slot], u, xk, cx, m.g, k == 0 ? n : 0u, k == N - 1 ? 2 * n : 3 * n, acc);
+            fma_unit<T, NCT, V, true>(ring[slot], u, xg, xl, cx, m.g, k == 0 ? n : 0u, k == N - 1 ? 2 * n : 3 * n, acc);
         } else {
-            fma_unit<T, NCT, V, false>(ring[slot], u, xk, cx, m.g, 0u, 3 * n, acc);
+            fma_unit<T, NCT, V, false>(ring[slot], u, xg, xl, cx, m.g, 0u, 3 * n, acc);
         }
         if (REFILL || refill) issue(q + DEPTH, slot, cx, n);
         if (Gm::UPR == 1 || u == Gm::UPR - 1) {
@@ -318,12 +342,40 @@ template <typename T, int NCT, int V> struct RowStream {
     }
 };
 
-// All-lanes sum of one value per lane (butterfly; every lane returns the total).
+// All-lanes sum of one value per lane; every lane returns the same total.
+// DPP row shifts / row broadcasts in the VALU (no LDS crossbar round trips): partial sums run up
+// each 16-lane row, rows 0,2 are broadcast into rows 1,3, row 1's total into the upper half, the
+// wave total lands in lane 63 and is read back as a scalar.  Fixed, data-independent order.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
+{
+    // lanes with no source (bound_ctrl off, old = 0) add 0
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_add(double v)
+{
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    const long long moved = ((long long)hi << 32) | (unsigned int)lo;
+    return v + __builtin_bit_cast(double, moved);
+}
 template <typename T> __device__ __forceinline__ T wave_sum(T v)
 {
-#pragma unroll
-    for (uint32_t off = kWave / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v = dpp_add<0x111>(v);  // row_shr:1
+    v = dpp_add<0x112>(v);  // row_shr:2
+    v = dpp_add<0x114>(v);  // row_shr:4
+    v = dpp_add<0x118>(v);  // row_shr:8   -> lane 15 of each row holds the row total
+    v = dpp_add<0x142>(v);  // row_bcast:15 -> rows 1 and 3 add the total of the row below
+    v = dpp_add<0x143>(v);  // row_bcast:31 -> upper half adds the lower half's total
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    } else {
+        const long long bits = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 63);
+        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
+    }
 }
 
 // Round an element count up so the next LDS array stays 16-byte aligned (Guideline 17).
