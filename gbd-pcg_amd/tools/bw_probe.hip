@@ -3,6 +3,7 @@
 //   read4   : pure streaming read, 16 B per lane (sum reduction)     -> the read ceiling
 //   read2   : pure streaming read, 8 B per lane, 63 of 64 lanes live -> what the n=14 lane map can reach
 //   spmv    : gbdpcg_spmv_f32 through the C ABI (the shipped kernel)
+// Every launch reads a matrix that 3 x 308 MB of other traffic has pushed out of the Infinity Cache.
 // Usage: bw_probe [batch=1024] [N=128] [reps=30]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -70,16 +71,22 @@ int main(int argc, char** argv)
     const uint32_t n = 14;
     const size_t melems = (size_t)3 * n * n * N * batch, velems = (size_t)n * N * batch;
     const size_t mbytes = melems * 4;
-    float *M[2], *x, *y, *out;
-    for (int i = 0; i < 2; ++i) { CK(hipMalloc(&M[i], mbytes)); CK(hipMemset(M[i], 0, mbytes)); }
-    CK(hipMalloc(&x, velems * 4)); CK(hipMalloc(&y, velems * 4)); CK(hipMalloc(&out, 256));
-    {   // non-trivial contents
+    // NB distinct matrices, visited round-robin: a buffer is re-read only after (NB-1)*mbytes of other
+    // traffic, so with NB*mbytes >> 256 MiB every launch streams from HBM, not from the Infinity Cache
+    const int NB = 4;
+    float *M[NB], *x, *y, *out;
+    {
         std::vector<float> h(melems);
-        for (size_t i = 0; i < melems; ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
-        CK(hipMemcpy(M[0], h.data(), mbytes, hipMemcpyHostToDevice));
-        for (size_t i = 0; i < melems; ++i) h[i] = -h[i];
-        CK(hipMemcpy(M[1], h.data(), mbytes, hipMemcpyHostToDevice));
-        std::vector<float> hx(velems, 1.0f);
+        for (int b = 0; b < NB; ++b) {
+            CK(hipMalloc(&M[b], mbytes));
+            for (size_t i = 0; i < melems; ++i) h[i] = (float)(((i + b) * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+            CK(hipMemcpy(M[b], h.data(), mbytes, hipMemcpyHostToDevice));
+        }
+    }
+    CK(hipMalloc(&x, velems * 4)); CK(hipMalloc(&y, velems * 4)); CK(hipMalloc(&out, 256));
+    {
+        std::vector<float> hx(velems);
+        for (size_t i = 0; i < velems; ++i) hx[i] = (float)((i * 40503u) & 0xfff) / 4096.f - 0.5f;
         CK(hipMemcpy(x, hx.data(), velems * 4, hipMemcpyHostToDevice));
     }
     gbdpcg_handle_t h;
@@ -90,9 +97,10 @@ int main(int argc, char** argv)
     const int NV = 5;
     const char* names[NV] = {"read4 (grid-stride)", "read4 (slab/WG)", "read2 63-lane", "spmv C-ABI", "read4 2048 WG"};
     std::vector<float> t[NV];
+    int turn = 0;
     for (int r = 0; r < reps + 3; ++r) {
         for (int v = 0; v < NV; ++v) {
-            const float* Mb = M[r & 1];
+            const float* Mb = M[turn++ % NB];
             CK(hipEventRecord(e0, s));
             switch (v) {
             case 0: hipLaunchKernelGGL(read4_kernel, dim3(256 * 16), dim3(256), 0, s, (const float4*)Mb, melems / 4, out); break;
@@ -107,7 +115,8 @@ int main(int argc, char** argv)
             if (r >= 3) t[v].push_back(ms);
         }
     }
-    printf("matrix bytes per launch: %.1f MB (batch %u, N %u)\n", mbytes / 1e6, batch, N);
+    printf("matrix bytes per launch: %.1f MB (batch %u, N %u), %d matrices visited round-robin (cold reads)\n",
+           mbytes / 1e6, batch, N, NB);
     for (int v = 0; v < NV; ++v) {
         const float ms = median(t[v]);
         const double bytes = v == 3 ? (double)batch * ((3.0 * N - 2) * n * n + 2.0 * n * N) * 4 : (double)mbytes;
