@@ -254,7 +254,7 @@ __device__ __forceinline__ void block_row_mv_rt(const T *__restrict__ Mk, const 
 // DEPTH-1 younger units (a conditionally primed ring makes its waitcnt pass assume the shortest
 // queue and drain every iteration).  The ring slot is a compile-time index (loops unrolled by
 // DEPTH); row and unit-in-row are runtime values that only enter address arithmetic.
-// NCT == 0 (runtime n): prime() does nothing and run() is a plain loop over rows.
+// NCT == 0 (runtime n) has its own specialisation below with the same pipeline and runtime geometry.
 template <typename T, int NCT, int V> struct RowStream {
     using Gm = StreamGeom<T, NCT, V>;
     static constexpr int DEPTH = Gm::DEPTH;
@@ -337,6 +337,109 @@ template <typename T, int NCT, int V> struct RowStream {
                                       k == N - 1 ? 2 * n : 3 * n, acc);
                 fold_groups<T, NCT, V>(m, acc);
                 on_row(k, acc);
+            }
+        }
+    }
+};
+
+// ---- runtime block size (NCT == 0): the same register-ring pipeline with runtime geometry ----------
+// Units are CH = 4 steps whatever n is (steps past the row's last one are masked: they re-read
+// element 0 and contribute 0), so the number of loads per unit -- what the counted waits rely on --
+// is still a compile-time constant; G, the step count and the units per row are runtime scalars.
+template <typename T, int V> struct StreamCtx<T, 0, V> {
+    uint32_t n, G, steps, upr, chunk;  // wave-uniform
+    uint32_t g, off_lane;              // per lane
+    bool active;
+    static constexpr uint32_t CH = 4;
+    __device__ __forceinline__ StreamCtx(const LaneMap<0, V> &m, uint32_t lane) {
+        n = m.n; G = m.G; steps = m.steps; upr = (m.steps + CH - 1) / CH; chunk = m.G * m.n;
+        g = m.g; active = m.active; off_lane = m.active ? lane * V : 0u;
+    }
+};
+
+template <typename T, int V> struct RowStream<T, 0, V> {
+    static constexpr uint32_t CH = StreamCtx<T, 0, V>::CH;
+    static constexpr int DEPTH = (CH * V * sizeof(T) / 4) <= 8 ? 4 : 3;
+    struct Unit { T a[CH][V]; };
+    Unit ring[DEPTH];
+    const T *M;
+    uint32_t k_begin, k_end, k_step, total;
+    uint32_t qi, ri_i, u_i;  // issue cursor: unit index, row index, unit-in-row
+
+    __device__ __forceinline__ void issue_next(int slot, const StreamCtx<T, 0, V> &cx) {
+        const uint32_t k = qi < total ? k_begin + ri_i * k_step : 0u;
+        const T *Mk = M + (size_t)k * 3 * cx.n * cx.n;
+#pragma unroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t s = u_i * CH + j;
+            const uint32_t c = cx.g + cx.G * s;
+            const bool ok = cx.active && s < cx.steps && c < 3 * cx.n;
+            VecIO<T, V>::load(Mk + (ok ? s * cx.chunk + cx.off_lane : 0u), ring[slot].a[j]);
+        }
+        ++qi;
+        if (++u_i == cx.upr) { u_i = 0; ++ri_i; }
+    }
+
+    __device__ __forceinline__ void prime(const T *__restrict__ M_, uint32_t k_begin_, uint32_t k_end_,
+                                          uint32_t k_step_, const StreamCtx<T, 0, V> &cx, uint32_t /*n*/) {
+        M = M_; k_begin = k_begin_; k_end = k_end_; k_step = k_step_;
+        const uint32_t nrows = k_end > k_begin ? (k_end - k_begin + k_step - 1) / k_step : 0;
+        total = nrows * cx.upr;
+        qi = 0; ri_i = 0; u_i = 0;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            issue_next(j, cx);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    template <typename RowFn>
+    __device__ __forceinline__ void consume(int slot, uint32_t ri, uint32_t u, const T *xw, uint32_t k_x0, uint32_t N,
+                                            const LaneMap<0, V> &m, const StreamCtx<T, 0, V> &cx, bool refill,
+                                            T (&acc)[V], RowFn &&on_row) {
+        const uint32_t n = cx.n;
+        const uint32_t k = k_begin + ri * k_step;
+        const T *xk = xw + (k - k_x0) * n;
+        const uint32_t c_lo = k == 0 ? n : 0u, c_hi = k == N - 1 ? 2 * n : 3 * n;
+#pragma unroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t s = u * CH + j;
+            const uint32_t c = cx.g + cx.G * s;
+            const bool keep = cx.active && s < cx.steps && c >= c_lo && c < c_hi;
+            const T xv = xk[c < 3 * n ? c : 3 * n - 1];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fma_t(keep ? ring[slot].a[j][v] : T(0), xv, acc[v]);
+        }
+        if (refill) issue_next(slot, cx);
+        if (u == cx.upr - 1) {
+            fold_groups<T, 0, V>(m, acc);
+            on_row(k, acc);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = T(0);
+        }
+    }
+
+    template <typename RowFn>
+    __device__ __forceinline__ void run(const T *xw, uint32_t k_x0, uint32_t N, const LaneMap<0, V> &m,
+                                        const StreamCtx<T, 0, V> &cx, uint32_t /*lane*/, RowFn &&on_row) {
+        T acc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = T(0);
+        uint32_t q0 = 0, ri = 0, u = 0;  // consume cursor
+        for (; q0 + 2 * DEPTH <= total; q0 += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                consume(j, ri, u, xw, k_x0, N, m, cx, true, acc, on_row);
+                if (++u == cx.upr) { u = 0; ++ri; }
+            }
+        }
+        for (; q0 < total; q0 += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                if (q0 + j < total) {
+                    consume(j, ri, u, xw, k_x0, N, m, cx, q0 + j + DEPTH < total, acc, on_row);
+                    if (++u == cx.upr) { u = 0; ++ri; }
+                }
             }
         }
     }

@@ -41,6 +41,19 @@ template <typename T> struct PcgArgs {
 // Returns 0 when no mapping exists (n/V > 64 for every V).
 template <typename T> int choose_vec(uint32_t n, const void *const *ptrs, int nptrs);
 
+// Block sizes with a compile-time specialised kernel (everything else runs the runtime-n pipeline).
+// BASELINE shapes (14, 36), the reference's example (2) and common MPC state sizes.
+#define GBDPCG_SPECIALIZED_N(X) X(2) X(4) X(6) X(8) X(12) X(13) X(14) X(16) X(18) X(24) X(36)
+
+// Widest per-lane vector a specialised kernel of block size NCT is built with (the V choose_vec
+// returns for aligned pointers); other V values of that n fall back to the runtime-n kernel.
+template <typename T, int NCT> constexpr int best_v()
+{
+    for (int V : {4, 2, 1})
+        if ((size_t)V * sizeof(T) <= 16 && NCT % V == 0 && NCT / V <= 64) return V;
+    return 1;
+}
+
 // ---- spmv.hip
 template <typename T> hipError_t launch_spmv(const DeviceInfo &dev, const SpmvArgs<T> &a, hipStream_t s);
 

@@ -400,11 +400,14 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
     if (V == 0) return hipErrorInvalidValue;
-    switch (a.n) {
-    case 14: return launch_fused_n<T, 14>(dev, a, V, s);
-    case 36: return launch_fused_n<T, 36>(dev, a, V, s);
-    default: return launch_fused_n<T, 0>(dev, a, V, s);
+    static const bool generic_only = getenv("GBDPCG_FORCE_GENERIC") != nullptr;  // tuning runs only
+    if (!generic_only) {
+#define GBDPCG_CASE(NN) \
+    if (a.n == NN && V == best_v<T, NN>()) return launch_fused_v<T, NN, best_v<T, NN>()>(dev, a, s);
+        GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
     }
+    return launch_fused_n<T, 0>(dev, a, V, s);
 }
 
 template size_t fused_lds_bytes<float>(uint32_t, uint32_t, uint32_t);

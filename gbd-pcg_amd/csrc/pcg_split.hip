@@ -21,6 +21,8 @@
 // chunk still reads in the same launch are double-buffered by iteration parity.  A per-problem
 // `done` word turns the launches after convergence into no-ops, which keeps the launch sequence
 // static and hipGraph-capturable.
+#include <cstdlib>
+
 #include "bt_device.hpp"
 #include "internal.hpp"
 
@@ -374,11 +376,14 @@ hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *wo
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
     if (V == 0 || workspace == nullptr) return hipErrorInvalidValue;
-    switch (a.n) {
-    case 14: return launch_split_n<T, 14>(dev, a, workspace, V, s);
-    case 36: return launch_split_n<T, 36>(dev, a, workspace, V, s);
-    default: return launch_split_n<T, 0>(dev, a, workspace, V, s);
+    static const bool generic_only = getenv("GBDPCG_FORCE_GENERIC") != nullptr;  // tuning runs only
+    if (!generic_only) {
+#define GBDPCG_CASE(NN) \
+    if (a.n == NN && V == best_v<T, NN>()) return launch_split_v<T, NN, best_v<T, NN>()>(dev, a, workspace, s);
+        GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
     }
+    return launch_split_n<T, 0>(dev, a, workspace, V, s);
 }
 
 template size_t split_workspace_bytes<float>(uint32_t, uint32_t, uint32_t);

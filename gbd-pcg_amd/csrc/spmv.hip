@@ -5,6 +5,8 @@
 // (rpw+2)*n halo window of x in LDS once, then each of its wavefronts streams whole block-rows
 // from HBM with stream_rows (bt_device.hpp).  Algorithmic bytes per problem:
 // ((3N-2) n^2 + 2 n N) sizeof(T)  (SURVEY.md section 8d).
+#include <cstdlib>
+
 #include "bt_device.hpp"
 #include "internal.hpp"
 
@@ -101,11 +103,14 @@ template <typename T> hipError_t launch_spmv(const DeviceInfo &dev, const SpmvAr
     const void *ptrs[] = {a.M};
     const int V = choose_vec<T>(a.n, ptrs, 1);
     if (V == 0) return hipErrorInvalidValue;
-    switch (a.n) {
-    case 14: return launch_spmv_n<T, 14>(dev, a, V, s);
-    case 36: return launch_spmv_n<T, 36>(dev, a, V, s);
-    default: return launch_spmv_n<T, 0>(dev, a, V, s);
+    static const bool generic_only = getenv("GBDPCG_FORCE_GENERIC") != nullptr;  // tuning runs only
+    if (!generic_only) {
+#define GBDPCG_CASE(NN) \
+    if (a.n == NN && V == best_v<T, NN>()) return launch_spmv_v<T, NN, best_v<T, NN>()>(dev, a, s);
+        GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
     }
+    return launch_spmv_n<T, 0>(dev, a, V, s);
 }
 
 template hipError_t launch_spmv<float>(const DeviceInfo &, const SpmvArgs<float> &, hipStream_t);
