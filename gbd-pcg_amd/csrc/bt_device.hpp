@@ -1,7 +1,7 @@
 // bt_device.hpp -- wavefront-level primitives for block-tridiagonal [L|D|R] matrices (gfx950).
 //
 // What replaces what (reference paths relative to /root/reference):
-//   stream_rows    <- loadbdVec + bdmv              (include/utils.cuh:9-85)
+//   RowStream      <- loadbdVec + bdmv              (include/utils.cuh:9-85)
 //   wave_sum       <- glass::dot / glass::reduce    (call sites include/pcg.cuh:144-149,163-169,187-193)
 //
 // Design (not a translation).  The reference gives one CUDA block to a knot and lets thread r

@@ -6,7 +6,7 @@
 // 4-26 us (MI355X_MICROARCH.md, barrier-xcd / barrier-cg), so this kernel turns the
 // decomposition around: the VECTORS (lambda, r, p, and the S p / Pinv r product) of one
 // problem live in one workgroup's LDS for the whole solve, S and Pinv are streamed from HBM
-// once per iteration by stream_rows, and both inner products are reduced inside the
+// once per iteration by RowStream, and both inner products are reduced inside the
 // workgroup (wave butterfly -> WAVES partials in LDS -> same-order sum in every thread, which
 // keeps the convergence branch uniform like pcg.cuh:147,167,191 do).  No cross-CU traffic at
 // all; each problem exits on its own iteration count.  Algorithmic HBM bytes per

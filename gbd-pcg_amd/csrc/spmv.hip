@@ -3,7 +3,7 @@
 // Replaces loadbdVec + bdmv (/root/reference/include/utils.cuh:9-85) as a standalone operator.
 // Work decomposition: a workgroup owns `rpw` consecutive block-rows of one problem; it stages the
 // (rpw+2)*n halo window of x in LDS once, then each of its wavefronts streams whole block-rows
-// from HBM with stream_rows (bt_device.hpp).  Algorithmic bytes per problem:
+// from HBM with RowStream (bt_device.hpp).  Algorithmic bytes per problem:
 // ((3N-2) n^2 + 2 n N) sizeof(T)  (SURVEY.md section 8d).
 #include <cstdlib>
 

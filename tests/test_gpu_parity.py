@@ -176,6 +176,22 @@ def test_fp32_vs_oracle(solver, orc, golden_dir, path, n, N):
 
 @pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 16, 18, 20, 24, 36, 37, 48])
+def test_state_sizes(solver, orc, path, dtype, n):
+    """Every block size: the compile-time specialised kernels (2, 4, 6, 8, 12, 13, 14, 16, 18, 24, 36)
+    and the runtime-n pipeline (the rest) against the oracle, lambda and iteration count."""
+    N, B = 11, 3
+    d = synth.gen_numpy(n, N, seed=300 + n, batch=B, dtype=dtype)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=60)
+    out = gpu_solve(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=60, path=path)
+    assert np.array_equal(out["iters"], ob["iters"]) and not out["max_iter_exit"].any()
+    tol = F64_TOL if dtype == np.float64 else F32_TOL
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol
+
+
+@pytest.mark.parametrize("path", PATHS, ids=PATH_NAME.get)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_batch_of_config3(solver, orc, golden_dir, path, dtype):
     """G6: eight problems of BASELINE config 3's batch (seeds 1234+i), solved as one batch."""
     G = np.load(os.path.join(golden_dir, "gen_14x128_batch8.npz"))
