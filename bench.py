@@ -113,10 +113,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # GBDPCG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box (every rank on cuda:0,
+    # aggregation on CPU tensors); the real multi-GPU run uses RCCL ("nccl") with one rank per GPU
+    backend = os.environ.get("GBDPCG_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    agg_device = "cuda" if backend == "nccl" else "cpu"
 
     n, N, B, iters = N_STATE, N_KNOTS, BATCH_PER_GPU, MAX_ITER
     solver = binding.Solver(local_rank)
@@ -154,7 +163,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     # RCCL over xGMI: throughput aggregation only (max elapsed, total problem-iterations)
-    elapsed, total_units = sharding.aggregate(elapsed, float(B * iters * args.steps), device="cuda")
+    elapsed, total_units = sharding.aggregate(elapsed, float(B * iters * args.steps), device=agg_device)
     assert int(it_out.min()) == iters and int(it_out.max()) == iters
     assert torch.isfinite(lam).all()
 
