@@ -77,6 +77,24 @@ __device__ __forceinline__ T sum_partials(const T *g, uint32_t count, T *stage, 
     return wave_sum(v);
 }
 
+// Two partial arrays in one pass (one global round trip, one barrier pair): returns sum(gA) in
+// *sa_out and sum(gB) in *sb_out.  `stage` holds 2*count elements.
+template <typename T>
+__device__ __forceinline__ void sum_partials2(const T *gA, const T *gB, uint32_t count, T *stage, uint32_t tid,
+                                              uint32_t nthreads, T *sa_out, T *sb_out)
+{
+    __syncthreads();
+    for (uint32_t i = tid; i < 2 * count; i += nthreads) stage[i] = i < count ? gA[i] : gB[i - count];
+    __syncthreads();
+    T va = T(0), vb = T(0);
+    for (uint32_t i = tid & 63u; i < count; i += 64) {
+        va += stage[i];
+        vb += stage[count + i];
+    }
+    *sa_out = wave_sum(va);
+    *sb_out = wave_sum(vb);
+}
+
 template <typename T, int WAVES>
 __device__ __forceinline__ void store_partial(T part, T *dst, T *red, uint32_t lane, uint32_t wave)
 {
@@ -92,10 +110,10 @@ __device__ __forceinline__ void store_partial(T part, T *dst, T *red, uint32_t l
     }
 }
 
-// LDS: window[(rpw+2)n] | stage[max(chunks, WAVES)] (16-byte aligned each)
+// LDS: window[(rpw+2)n] | stage[2*max(chunks, WAVES)] | red[WAVES] (16-byte aligned each)
 template <typename T> __host__ __device__ inline size_t split_lds_elems(uint32_t n, uint32_t rpw, uint32_t chunks)
 {
-    return align16<T>((rpw + 2) * n) + align16<T>(chunks > (uint32_t)kSplitWaves ? chunks : kSplitWaves) +
+    return align16<T>((rpw + 2) * n) + align16<T>(2 * (chunks > (uint32_t)kSplitWaves ? chunks : kSplitWaves)) +
            align16<T>(kSplitWaves);
 }
 
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
 
     T *win = reinterpret_cast<T *>(smem_raw);
     T *stage = win + align16<T>((sa.rpw + 2) * n);
-    T *red = stage + align16<T>(sa.chunks > (uint32_t)WAVES ? sa.chunks : WAVES);
+    T *red = stage + align16<T>(2 * (sa.chunks > (uint32_t)WAVES ? sa.chunks : WAVES));
 
     const SplitWs<T> w(n, N);
     T *ws = sa.ws + (size_t)prob * w.per_problem;
@@ -171,13 +189,28 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                 win[i] = (gi >= 0 && gi < (int64_t)len) ? rbuf[1][gi] : T(0);
             }
         } else {
-            // eta = r.r~ of the previous half-step lives in pe[par^1]; v = p.ups in pv
-            const T eta = sum_partials(pe[par ^ 1], sa.chunks, stage, tid, THREADS);
-            const T v = sum_partials(pv, sa.chunks, stage, tid, THREADS);
-            const T alpha = eta / v;
+            // eta = r.r~ of the previous half-step lives in pe[par^1]; v = p.ups in pv.
+            // The first window element of every thread is fetched BEFORE the partial sums: the two
+            // global round trips overlap instead of following each other.
             const T *r_old = rbuf[par ^ 1];
             const T *p_cur = pbuf[par];
-            for (uint32_t i = tid; i < cnt; i += THREADS) {
+            const int64_t gi0 = g0 + tid;
+            const bool in0 = tid < cnt && gi0 >= 0 && gi0 < (int64_t)len;
+            const bool own0 = in0 && tid >= own_lo && tid < own_hi;
+            const T r0 = in0 ? r_old[gi0] : T(0), u0 = in0 ? ups[gi0] : T(0);
+            const T p0 = own0 ? p_cur[gi0] : T(0), l0 = own0 ? lambda[gi0] : T(0);
+            T eta, v;
+            sum_partials2(pe[par ^ 1], pv, sa.chunks, stage, tid, THREADS, &eta, &v);
+            const T alpha = eta / v;
+            if (tid < cnt) {
+                const T rv = in0 ? fma_t(-alpha, u0, r0) : T(0);
+                if (own0) {
+                    rbuf[par][gi0] = rv;
+                    lambda[gi0] = fma_t(alpha, p0, l0);
+                }
+                win[tid] = rv;
+            }
+            for (uint32_t i = tid + THREADS; i < cnt; i += THREADS) {
                 const int64_t gi = g0 + i;
                 T rv = T(0);
                 if (gi >= 0 && gi < (int64_t)len) {
@@ -193,7 +226,6 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
         M = P;
         out = rt;
     } else {  // PH_DIRECTION
-        const T eta_new = sum_partials(pe[par ^ 1], sa.chunks, stage, tid, THREADS);
         if (iter == 0) {
             for (uint32_t i = tid; i < cnt; i += THREADS) {
                 const int64_t gi = g0 + i;
@@ -205,6 +237,12 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                 win[i] = pn;
             }
         } else {
+            const T *p_old = pbuf[par ^ 1];
+            const int64_t gi0 = g0 + tid;
+            const bool in0 = tid < cnt && gi0 >= 0 && gi0 < (int64_t)len;
+            const T q0 = in0 ? p_old[gi0] : T(0), t0 = in0 ? rt[gi0] : T(0);  // fetched before the sums
+            T eta_new, eta;
+            sum_partials2(pe[par ^ 1], pe[par], sa.chunks, stage, tid, THREADS, &eta_new, &eta);
             if (fabs(eta_new) < a.tol) {  // iteration iter-1 converged (pcg.cuh:195)
                 if (chunk == 0 && tid == 0) {
                     sa.done[prob] = 1;
@@ -213,10 +251,13 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                 }
                 return;
             }
-            const T eta = sum_partials(pe[par], sa.chunks, stage, tid, THREADS);
             const T beta = eta_new / eta;
-            const T *p_old = pbuf[par ^ 1];
-            for (uint32_t i = tid; i < cnt; i += THREADS) {
+            if (tid < cnt) {
+                const T pn = in0 ? fma_t(beta, q0, t0) : T(0);
+                if (in0 && tid >= own_lo && tid < own_hi) pbuf[par][gi0] = pn;
+                win[tid] = pn;
+            }
+            for (uint32_t i = tid + THREADS; i < cnt; i += THREADS) {
                 const int64_t gi = g0 + i;
                 T pn = T(0);
                 if (gi >= 0 && gi < (int64_t)len) {
@@ -261,14 +302,15 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
 
 // After the last iteration: final convergence test (pcg.cuh:195 for iteration max_iter-1),
 // iters / max_iter_exit (pcg.cuh:212), and r, p copied to the caller's buffers.
+// grid = batch * fchunks workgroups; each redoes the (cheap) test and copies its 1024-element slice.
 template <typename T>
-__global__ __launch_bounds__(256) void pcg_split_finish(SplitArgs<T> sa)
+__global__ __launch_bounds__(256) void pcg_split_finish(SplitArgs<T> sa, uint32_t fchunks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *stage = reinterpret_cast<T *>(smem_raw);
     const PcgArgs<T> &a = sa.a;
     const uint32_t n = a.n, N = a.N, len = n * N;
-    const uint32_t prob = blockIdx.x, tid = threadIdx.x;
+    const uint32_t prob = blockIdx.x / fchunks, fc = blockIdx.x - prob * fchunks, tid = threadIdx.x;
     const SplitWs<T> w(n, N);
     T *ws = sa.ws + (size_t)prob * w.per_problem;
     const size_t L = align16<T>(len), Q = align16<T>(w.npart);
@@ -282,15 +324,16 @@ __global__ __launch_bounds__(256) void pcg_split_finish(SplitArgs<T> sa)
         iters = a.max_iter;
         bool exit_flag = true;
         if (a.max_iter > 0) {
-            const T eta_new = sum_partials(ws + w.pe + ((a.max_iter - 1) & 1) * Q, sa.chunks, stage, tid, 256);
+            T eta_new, eta;
+            sum_partials2(ws + w.pe + ((a.max_iter - 1) & 1) * Q, ws + w.pe + (a.max_iter & 1) * Q, sa.chunks, stage, tid,
+                          256u, &eta_new, &eta);
             exit_flag = !(fabs(eta_new) < a.tol);
             if (exit_flag) {
-                const T eta = sum_partials(ws + w.pe + (a.max_iter & 1) * Q, sa.chunks, stage, tid, 256);
                 beta = eta_new / eta;
                 update_p = true;
             }
         }
-        if (tid == 0) {
+        if (fc == 0 && tid == 0) {
             a.iters[prob] = iters;
             if (a.max_iter_exit) a.max_iter_exit[prob] = exit_flag ? 1 : 0;
         }
@@ -299,7 +342,8 @@ __global__ __launch_bounds__(256) void pcg_split_finish(SplitArgs<T> sa)
     const T *r_fin = ws + w.r0 + (iters == 0 ? 1 : ((iters - 1) & 1)) * L;
     const T *p_last = iters == 0 ? ws + w.rt : ws + w.p0 + ((iters - 1) & 1) * L;
     const T *rt = ws + w.rt;
-    for (uint32_t i = tid; i < len; i += 256) {
+    const uint32_t lo = fc * 1024u, hi = min(len, lo + 1024u);
+    for (uint32_t i = lo + tid; i < hi; i += 256) {
         if (a.r) a.r[(size_t)prob * len + i] = r_fin[i];
         if (a.p) a.p[(size_t)prob * len + i] = update_p ? fma_t(beta, p_last[i], rt[i]) : p_last[i];
     }
@@ -352,8 +396,9 @@ static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, voi
         hipLaunchKernelGGL(k_dir, grid, block, lds, s, sa, (int)it);
         hipLaunchKernelGGL(k_pre, grid, block, lds, s, sa, (int)it);
     }
-    const size_t lds_fin = align16<T>(sa.chunks) * sizeof(T);
-    hipLaunchKernelGGL(pcg_split_finish<T>, dim3(a.batch), dim3(256), lds_fin, s, sa);
+    const size_t lds_fin = align16<T>(2 * sa.chunks) * sizeof(T);
+    const uint32_t fchunks = ((uint32_t)a.n * a.N + 1023u) / 1024u;
+    hipLaunchKernelGGL(pcg_split_finish<T>, dim3(a.batch * fchunks), dim3(256), lds_fin, s, sa, fchunks);
     return hipGetLastError();
 }
 

@@ -1,0 +1,147 @@
+"""GPU edge cases of the C ABI: argument validation, unsupported shapes, misaligned pointers (narrower
+vector width fallback), persistent workgroups (batch larger than the grid), long horizons that do not
+fit one workgroup's LDS (automatic split path), non-default streams, occupancy check."""
+import ctypes
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from gbd_pcg_amd import binding, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver():
+    s = binding.Solver(0)
+    yield s
+    s.close()
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_invalid_arguments_return_status(solver):
+    lib, h = solver.lib, solver.h
+    z = torch.zeros(64, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    f0 = ctypes.c_float(1e-6)
+    # n == 0, N == 0, batch == 0, null S, null iters
+    assert lib.gbdpcg_solve_f32(h, 0, 3, 1, p(z), None, p(z), p(z), None, None, f0, 5, p(it), None, None) == 1
+    assert lib.gbdpcg_solve_f32(h, 2, 0, 1, p(z), None, p(z), p(z), None, None, f0, 5, p(it), None, None) == 1
+    assert lib.gbdpcg_solve_f32(h, 2, 3, 0, p(z), None, p(z), p(z), None, None, f0, 5, p(it), None, None) == 1
+    assert lib.gbdpcg_solve_f32(h, 2, 3, 1, None, None, p(z), p(z), None, None, f0, 5, p(it), None, None) == 1
+    assert lib.gbdpcg_solve_f32(h, 2, 3, 1, p(z), None, p(z), p(z), None, None, f0, 5, None, None, None) == 1
+    assert lib.gbdpcg_spmv_f32(h, 2, 3, 1, p(z), None, p(z), None) == 1
+    # a block size no lane map covers: odd n > 64 (n/V > 64 for every V)
+    assert lib.gbdpcg_spmv_f32(h, 67, 2, 1, p(z), p(z), p(z), None) == 4      # GBDPCG_ERR_UNSUPPORTED
+    assert lib.gbdpcg_check_occupancy(h, 4, 67, 2, 1) == 4
+    assert lib.gbdpcg_check_occupancy(h, 4, 14, 128, 1024) == 0
+    assert lib.gbdpcg_check_occupancy(h, 8, 36, 256, 1) == 0                  # split path, fits
+    assert lib.gbdpcg_check_occupancy(h, 3, 14, 8, 1) == 1                    # elem_size must be 4 or 8
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_misaligned_matrix_pointers_use_narrower_loads(solver, orc, dtype):
+    """S / Pinv offset by one element: only V = 1 loads are legal; results must not change."""
+    n, N, B = 14, 12, 2
+    d = synth.gen_numpy(n, N, seed=91, batch=B, dtype=dtype)
+    es = np.dtype(dtype).itemsize
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    bufS = torch.zeros(d["S"].size + 1, dtype=tdt, device="cuda")
+    bufP = torch.zeros(d["Pinv"].size + 1, dtype=tdt, device="cuda")
+    S, P = bufS[1:], bufP[1:]
+    assert S.data_ptr() % (2 * es) != 0
+    S.copy_(dev(d["S"]).reshape(-1))
+    P.copy_(dev(d["Pinv"]).reshape(-1))
+    g = dev(d["gamma"])
+    for path in (binding.PATH_FUSED, binding.PATH_SPLIT):
+        solver.set_path(path)
+        lam = torch.zeros_like(g)
+        iters, flags = solver.solve(n, N, B, S, P, g, lam, tol=1e-6, max_iter=50)
+        torch.cuda.synchronize()
+        ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=50)
+        assert np.array_equal(iters.cpu().numpy(), ob["iters"].astype(np.int32))
+        lam_h = lam.cpu().numpy().reshape(B, -1)
+        for b in range(B):
+            assert relerr(lam_h[b], ob["lambda_"][b]) < (1e-10 if dtype == np.float64 else 1e-6)
+    solver.set_path(binding.PATH_AUTO)
+    x = torch.randn(B * n * N, dtype=tdt, device="cuda")
+    y = solver.spmv(n, N, B, S, x)
+    y_ref = solver.spmv(n, N, B, dev(d["S"]).reshape(-1), x)
+    torch.cuda.synchronize()
+    assert relerr(y.cpu().numpy(), y_ref.cpu().numpy()) < 1e-6
+
+
+def test_batch_larger_than_grid(solver, orc):
+    """More problems than resident workgroups: the fused kernel's persistent loop must visit all."""
+    n, N, B = 6, 5, 3000
+    base = synth.gen_numpy(n, N, seed=17, batch=8, dtype=np.float64)
+    idx = np.arange(B) % 8
+    S, P, g = base["S"][idx], base["Pinv"][idx], base["gamma"][idx] * (1.0 + 0.001 * np.arange(B))[:, None]
+    solver.set_path(binding.PATH_FUSED)
+    lam = torch.zeros((B, n * N), dtype=torch.float64, device="cuda")
+    iters, flags = solver.solve(n, N, B, dev(S), dev(P), dev(g), lam, tol=1e-22, max_iter=60)
+    torch.cuda.synchronize()
+    solver.set_path(binding.PATH_AUTO)
+    assert flags.sum().item() == 0
+    lam = lam.cpu().numpy()
+    for b in (0, 1, 7, 8, 1023, 1024, 2047, 2999):
+        A = orc.dense_from_bt(n, N, S[b])
+        assert relerr(lam[b], np.linalg.solve(A, g[b])) < 1e-8
+
+
+def test_long_horizon_goes_split_automatically(solver, orc):
+    """n=14, N=1200 fp64: four vectors of 134 KB exceed one workgroup's LDS -> AUTO picks the split path."""
+    n, N = 14, 1200
+    assert solver.choose_path(8, n, N, 1) == binding.PATH_SPLIT
+    d = synth.gen_numpy(n, N, seed=23, dtype=np.float64)
+    lam = torch.zeros(n * N, dtype=torch.float64, device="cuda")
+    iters, flags = solver.solve(n, N, 1, dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"]), lam, tol=1e-6, max_iter=60)
+    torch.cuda.synchronize()
+    o = orc.pcg(n, N, d["S"][0], d["Pinv"][0], d["gamma"][0], tol=1e-6, max_iter=60)
+    assert int(iters[0]) == o["iters"] and relerr(lam.cpu().numpy(), o["lambda_"]) < 1e-10
+
+
+@pytest.mark.parametrize("path", [binding.PATH_FUSED, binding.PATH_SPLIT])
+def test_non_default_stream(solver, orc, path):
+    n, N, B = 14, 10, 5
+    d = synth.gen_numpy(n, N, seed=29, batch=B, dtype=np.float32)
+    s = torch.cuda.Stream()
+    S, P, g = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+    lam = torch.zeros_like(g)
+    torch.cuda.synchronize()
+    solver.set_path(path)
+    with torch.cuda.stream(s):
+        iters, flags = solver.solve(n, N, B, S, P, g, lam, tol=1e-6, max_iter=50, stream=s)
+    s.synchronize()
+    solver.set_path(binding.PATH_AUTO)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=50)
+    assert np.array_equal(iters.cpu().numpy(), ob["iters"].astype(np.int32))
+    for b in range(B):
+        assert relerr(lam.cpu().numpy()[b], ob["lambda_"][b]) < 1e-6
+
+
+def test_register_resident_path_limits(solver, orc):
+    """n=14 fp32: N <= 72 runs register-resident, N = 73 streams; both must agree with the oracle
+    (N = 63, 64, 72, 73 straddle the wave / workgroup boundaries of the resident lane map)."""
+    n = 14
+    for N in (1, 2, 9, 10, 63, 64, 72, 73):
+        d = synth.gen_numpy(n, N, seed=400 + N, batch=2, dtype=np.float32)
+        lam = torch.zeros((2, n * N), dtype=torch.float32, device="cuda")
+        iters, flags = solver.solve(n, N, 2, dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"]), lam, tol=1e-6, max_iter=60)
+        torch.cuda.synchronize()
+        ob = orc.pcg_batch(n, N, 2, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=60)
+        assert np.array_equal(iters.cpu().numpy(), ob["iters"].astype(np.int32)), N
+        for b in range(2):
+            assert relerr(lam.cpu().numpy()[b], ob["lambda_"][b]) < 1e-6, N
