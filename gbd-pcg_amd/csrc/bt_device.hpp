@@ -89,7 +89,8 @@ template <int NCT, int V> struct LaneMap {
     }
 };
 
-// Compile-time geometry of the pipelined stream (NCT > 0 only).
+// Compile-time geometry of the pipelined stream (NCT > 0; for NCT == 0 these are placeholders
+// and the runtime geometry lives in StreamCtx<T, 0, V>).
 template <typename T, int NCT, int V> struct StreamGeom {
     static constexpr uint32_t N_ = NCT > 0 ? NCT : 1;
     static constexpr uint32_t RPC = N_ / V > 0 ? N_ / V : 1;
@@ -212,28 +213,6 @@ __device__ __forceinline__ void fold_groups_multi(const LaneMap<NCT, V> &m, T (&
     }
 }
 
-// Non-pipelined block-row product for runtime n (NCT == 0).
-template <typename T, int V>
-__device__ __forceinline__ void block_row_mv_rt(const T *__restrict__ Mk, const T *xk, const LaneMap<0, V> &m,
-                                                uint32_t lane, uint32_t c_lo, uint32_t c_hi, T (&acc)[V])
-{
-#pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = T(0);
-    const uint32_t chunk = m.G * m.n;
-    const T *src = Mk + lane * V;
-#pragma unroll 4
-    for (uint32_t s = 0; s < m.steps; ++s) {
-        const uint32_t c = m.g + m.G * s;
-        if (m.active && c >= c_lo && c < c_hi) {
-            T a[V];
-            VecIO<T, V>::load(src + s * chunk, a);
-            const T xv = xk[c];
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = fma_t(a[v], xv, acc[v]);
-        }
-    }
-}
-
 // RowStream: stream the block-rows k = k_begin, k_begin + k_step, ... < k_end of one problem
 // through this wavefront, in two calls so that the first matrix loads are already in flight while
 // the caller still prepares the x operand (LDS staging, reductions, barriers):
@@ -276,12 +255,10 @@ template <typename T, int NCT, int V> struct RowStream {
         k_step = k_step_;
         const uint32_t nrows = k_end > k_begin ? (k_end - k_begin + k_step - 1) / k_step : 0;
         total = nrows * Gm::UPR;
-        if constexpr (NCT > 0) {
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
-                issue((uint32_t)j, j, cx, n);
-                __builtin_amdgcn_sched_barrier(0);  // keep units in issue order: the waits count on it
-            }
+        for (int j = 0; j < DEPTH; ++j) {
+            issue((uint32_t)j, j, cx, n);
+            __builtin_amdgcn_sched_barrier(0);  // keep units in issue order: the waits count on it
         }
     }
 
@@ -310,33 +287,22 @@ template <typename T, int NCT, int V> struct RowStream {
 
     template <typename RowFn>
     __device__ __forceinline__ void run(const T *xw, uint32_t k_x0, uint32_t N, const LaneMap<NCT, V> &m,
-                                        const StreamCtx<T, NCT, V> &cx, uint32_t lane, RowFn &&on_row) {
-        if constexpr (NCT > 0) {
-            T acc[V];
+                                        const StreamCtx<T, NCT, V> &cx, uint32_t /*lane*/, RowFn &&on_row) {
+        T acc[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = T(0);
-            uint32_t q0 = 0;
-            // steady state: every consumed slot is refilled
-            for (; q0 + 2 * DEPTH <= total; q0 += DEPTH) {
+        for (int v = 0; v < V; ++v) acc[v] = T(0);
+        uint32_t q0 = 0;
+        // steady state: every consumed slot is refilled
+        for (; q0 + 2 * DEPTH <= total; q0 += DEPTH) {
 #pragma unroll
-                for (int j = 0; j < DEPTH; ++j) consume<true>(q0 + j, j, xw, k_x0, N, m, cx, true, acc, on_row);
-            }
-            // drain: at most 2*DEPTH-1 units left
-            for (; q0 < total; q0 += DEPTH) {
+            for (int j = 0; j < DEPTH; ++j) consume<true>(q0 + j, j, xw, k_x0, N, m, cx, true, acc, on_row);
+        }
+        // drain: at most 2*DEPTH-1 units left
+        for (; q0 < total; q0 += DEPTH) {
 #pragma unroll
-                for (int j = 0; j < DEPTH; ++j) {
-                    const uint32_t q = q0 + j;
-                    if (q < total) consume<false>(q, j, xw, k_x0, N, m, cx, q + DEPTH < total, acc, on_row);
-                }
-            }
-        } else {
-            const uint32_t n = m.n;
-            for (uint32_t k = k_begin; k < k_end; k += k_step) {
-                T acc[V];
-                block_row_mv_rt<T, V>(M + (size_t)k * 3 * n * n, xw + (k - k_x0) * n, m, lane, k == 0 ? n : 0u,
-                                      k == N - 1 ? 2 * n : 3 * n, acc);
-                fold_groups<T, NCT, V>(m, acc);
-                on_row(k, acc);
+            for (int j = 0; j < DEPTH; ++j) {
+                const uint32_t q = q0 + j;
+                if (q < total) consume<false>(q, j, xw, k_x0, N, m, cx, q + DEPTH < total, acc, on_row);
             }
         }
     }
