@@ -62,6 +62,11 @@ template <typename T> size_t fused_lds_bytes(uint32_t n, uint32_t N, uint32_t wa
 template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_t N);
 template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s);
 
+// ---- pcg_resident.hip : both matrices register-resident, one 8-wave workgroup per problem.
+// Returns false when the shape is not eligible (then nothing was launched).
+template <typename T>
+bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
+
 // ---- pcg_split.hip : many workgroups per problem, two launches per iteration
 template <typename T> size_t split_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
 template <typename T>

@@ -60,96 +60,6 @@ __device__ __forceinline__ T wg_spmv_dot(RowStream<T, NCT, V> &rs, const T *X, T
     return part;
 }
 
-// ---- register-resident matrices (small problems, e.g. BASELINE config 2: n=14, N=64) ---------------
-// When both matrices of a problem fit the register file of ONE 8-wave workgroup they are read from
-// HBM exactly once and an iteration touches only LDS.  This is the reference's own idea (its
-// block-rows sit in shared memory for the whole solve, pcg.cuh:104-110) moved one level up the
-// hierarchy, with the whole problem inside one workgroup so that no grid barrier exists.
-//
-// Lane map (different from the streaming one, where every instruction must be a dense global read):
-// a lane owns V whole ROWS of one block-row -- all 3n columns, 3n*V registers per matrix -- so a
-// block-row product is 3n FMAs per row with NO cross-lane fold, columns accumulated in ascending
-// order exactly like bdmv (utils.cuh:77-81).  n/V lanes make a block-row, BPW = 64/(n/V) block-rows
-// make a wave (n=14, V=2: 7 lanes x 9 block-rows = 63 lanes; the reference keeps n of 64 threads
-// busy), 8 waves cover N <= 8*BPW knots.  x is read from LDS as 8/16-byte pairs shared by the lanes
-// of a block-row.  Edge columns (L_0, R_{N-1}) and rows past N are zeroed once, at load time.
-template <typename T, int NCT, int V> struct DenseGeom {
-    static constexpr uint32_t N_ = NCT > 0 ? NCT : 2;
-    static constexpr uint32_t LPB = N_ / V > 0 ? N_ / V : 1;  // lanes per block-row
-    static constexpr uint32_t BPW = kWave / LPB;        // block-rows per wave
-    static constexpr uint32_t COLS = 3 * N_;
-    static constexpr uint32_t REGS = COLS * V * sizeof(T) / 4;  // VGPRs per lane per matrix
-    static constexpr uint32_t WAVES = 8;
-    static constexpr uint32_t MAX_KNOTS = WAVES * BPW;
-};
-
-template <typename T, int NCT, int V> struct DenseTile {
-    T a[DenseGeom<T, NCT, V>::COLS][V];
-};
-
-template <typename T, int NCT, int V> struct DenseCtx {
-    uint32_t k;       // this lane's block-row
-    uint32_t rp;      // row group inside it
-    bool live;        // lane maps to a real row of a real block-row
-    __device__ __forceinline__ DenseCtx(uint32_t wave, uint32_t lane, uint32_t N) {
-        using Dg = DenseGeom<T, NCT, V>;
-        const uint32_t b = lane / Dg::LPB;
-        rp = lane - b * Dg::LPB;
-        k = wave * Dg::BPW + b;
-        live = b < Dg::BPW && k < N;
-    }
-};
-
-template <typename T, int NCT, int V>
-__device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, const DenseCtx<T, NCT, V> &dc,
-                                           DenseTile<T, NCT, V> &tl)
-{
-    using Dg = DenseGeom<T, NCT, V>;
-    const uint32_t k = dc.live ? dc.k : 0u;
-    const T *src = M + (size_t)k * 3 * Dg::N_ * Dg::N_ + dc.rp * V;
-    const uint32_t c_lo = dc.k == 0 ? Dg::N_ : 0u, c_hi = dc.k == N - 1 ? 2 * Dg::N_ : 3 * Dg::N_;
-#pragma unroll
-    for (uint32_t c = 0; c < Dg::COLS; ++c) {
-        T v[V];
-        VecIO<T, V>::load(src + c * Dg::N_, v);
-        const bool keep = dc.live && c >= c_lo && c < c_hi;
-#pragma unroll
-        for (int j = 0; j < V; ++j) tl.a[c][j] = keep ? v[j] : T(0);
-    }
-}
-
-// y_k = [L|D|R]_k * X-window for this lane's rows; returns the lane's partial of dot(y, D).
-template <typename T, int NCT, int V>
-__device__ __forceinline__ T dense_spmv_dot(const DenseTile<T, NCT, V> &tl, const T *X, T *Y, const T *D,
-                                            const DenseCtx<T, NCT, V> &dc)
-{
-    using Dg = DenseGeom<T, NCT, V>;
-    using P2 = typename VecOf<T, 2>::type;
-    const uint32_t k = dc.live ? dc.k : 0u;
-    const P2 *xk = reinterpret_cast<const P2 *>(X + k * Dg::N_);  // column c of row k multiplies X[k*n + c]
-    T acc[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = T(0);
-#pragma unroll
-    for (uint32_t c = 0; c < Dg::COLS; c += 2) {
-        const P2 xv = xk[c / 2];
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fma_t(tl.a[c][j], xv.x, acc[j]);
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fma_t(tl.a[c + 1][j], xv.y, acc[j]);
-    }
-    T part = T(0);
-    if (dc.live) {
-        const uint32_t row = dc.k * Dg::N_ + dc.rp * V;
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            Y[row + j] = acc[j];
-            part = fma_t(acc[j], D[Dg::N_ + row + j], part);
-        }
-    }
-    return part;
-}
-
 // Workgroup-wide sum of per-lane partials; every thread returns the same bits.
 // Ends with a barrier-protected read, so Y written before the call is visible after it.
 template <typename T, int WAVES>
@@ -164,9 +74,7 @@ __device__ __forceinline__ T wg_sum(T part, T *red, uint32_t lane, uint32_t wave
     return tot;
 }
 
-// RES == 0: matrices streamed every iteration.  RES == 1: matrices register-resident (see above;
-// V is then the resident map's rows per lane and WAVES must be DenseGeom::WAVES).
-template <typename T, int NCT, int V, int WAVES, int RES>
+template <typename T, int NCT, int V, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -184,8 +92,6 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     const LaneMap<NCT, V> m(n, lane);
     const StreamCtx<T, NCT, V> cx(m, lane);
     RowStream<T, NCT, V> rs;
-    DenseTile<T, NCT, V> tS, tP;
-    const DenseCtx<T, NCT, V> dc(wave, lane, N);
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
@@ -195,12 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
         T *lambda = a.lambda + (size_t)prob * len;
 
         // first matrix loads go out before anything else touches memory
-        if constexpr (RES) {
-            dense_load<T, NCT, V>(S, N, dc, tS);
-            if (P) dense_load<T, NCT, V>(P, N, dc, tP);
-        } else {
-            rs.prime(S, wave, N, WAVES, cx, n);
-        }
+        rs.prime(S, wave, N, WAVES, cx, n);
         for (uint32_t i = tid; i < n; i += THREADS) {
             xa[i] = T(0); xa[n + len + i] = T(0);
             xb[i] = T(0); xb[n + len + i] = T(0);
@@ -228,9 +129,7 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
             const bool precond = phase & 1u;
             const T *X = precond ? xb : xa;
 #ifndef GBDPCG_EARLY_PRIME
-            if constexpr (!RES) {
-                if (phase > 0 && !(precond && !P)) rs.prime(precond ? P : S, wave, N, WAVES, cx, n);
-            }
+            if (phase > 0 && !(precond && !P)) rs.prime(precond ? P : S, wave, N, WAVES, cx, n);
 #endif
             T part = T(0);
             if (precond && !P) {  // identity preconditioner: r~ = r (the primed S units stay in flight)
@@ -238,12 +137,6 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
                     const T rv = xb[n + i];
                     yc[i] = rv;
                     part = fma_t(rv, rv, part);
-                }
-            } else if constexpr (RES) {
-                if (precond) {
-                    part = dense_spmv_dot<T, NCT, V>(tP, xb, yc, xb, dc);
-                } else {
-                    part = dense_spmv_dot<T, NCT, V>(tS, xa, yc, xa, dc);
                 }
             } else {
                 part = wg_spmv_dot<T, NCT, V>(rs, X, yc, X, m, cx, n, N, lane);
@@ -312,12 +205,12 @@ template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_
     return fused_lds_bytes<T>(n, N, 16) <= dev.lds_per_wg_max;
 }
 
-template <typename T, int NCT, int V, int WAVES, int RES = 0>
+template <typename T, int NCT, int V, int WAVES>
 static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
 {
     const size_t lds = fused_lds_bytes<T>(a.n, a.N, WAVES);
     if (lds > dev.lds_per_wg_max) return hipErrorInvalidValue;
-    auto kern = pcg_fused_kernel<T, NCT, V, WAVES, RES>;
+    auto kern = pcg_fused_kernel<T, NCT, V, WAVES>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -325,7 +218,7 @@ static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hip
     }
     // persistent over problems: at most as many workgroups as can be resident
     uint32_t per_cu = (uint32_t)(dev.lds_per_cu / lds);
-    const uint32_t by_waves = RES ? 1 : 32 / WAVES;  // a resident workgroup owns the CU's register file
+    const uint32_t by_waves = 32 / WAVES;
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu == 0) per_cu = 1;
     uint32_t grid = (uint32_t)dev.num_cus * per_cu;
@@ -375,28 +268,10 @@ static hipError_t launch_fused_n(const DeviceInfo &dev, const PcgArgs<T> &a, int
     return hipErrorInvalidValue;
 }
 
-// Register-resident path for n = 14, fp32: 2 rows per lane, 168 VGPRs of matrix, N <= 72 (the fp64
-// map -- 1 row per lane, N <= 32 -- is written but disabled: it spills).  Taken whenever the shape fits: the matrices are
-// then read once per solve instead of once per iteration.  GBDPCG_NO_RESIDENT disables it (tuning).
-template <typename T> static bool try_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
-{
-    static const bool off = getenv("GBDPCG_NO_RESIDENT") != nullptr;
-    if (off || a.n != 14) return false;
-    if (sizeof(T) == 8) return false;  // fp64: 168 matrix VGPRs + fp64 working set spills (measured 116 B/lane)
-    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
-    using Dg = DenseGeom<T, 14, RV>;
-    static_assert(2 * Dg::REGS <= 176, "resident matrices must leave registers for the solve");
-    if (a.N > Dg::MAX_KNOTS) return false;
-    const uintptr_t al = RV * sizeof(T);
-    if ((reinterpret_cast<uintptr_t>(a.S) % al) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % al)) return false;
-    *err = launch_fused_w<T, 14, RV, Dg::WAVES, 1>(dev, a, s);
-    return true;
-}
-
 template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
 {
     hipError_t rerr = hipSuccess;
-    if (try_resident<T>(dev, a, s, &rerr)) return rerr;
+    if (launch_pcg_resident<T>(dev, a, s, &rerr)) return rerr;  // small problems: pcg_resident.hip
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
     if (V == 0) return hipErrorInvalidValue;
