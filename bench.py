@@ -81,13 +81,12 @@ def cpu_baseline(n, N, iters, budget_s=12.0):
     from gbd_pcg_amd import synth
     from oracle import oracle as orc
     cores = host_cores()
-    probe = max(cores, 8)
+    probe = max(4 * cores, 32)
     d = synth.gen_numpy(n, N, seed=1234, batch=probe, dtype=np.float32)
     t0 = time.perf_counter()
     orc.pcg_batch(n, N, probe, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=iters, nthreads=cores)
     t_probe = time.perf_counter() - t0
-    reps = max(1, int(budget_s / max(t_probe, 1e-3)))
-    reps = min(reps, 64)
+    reps = max(1, min(int(budget_s / max(t_probe, 1e-4)), 20000))
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.pcg_batch(n, N, probe, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=iters, nthreads=cores)
