@@ -22,7 +22,8 @@ PINV_IDENTITY, PINV_BLOCK_JACOBI, PINV_STAIR = 0, 1, 2
 # every symbol include/gbdpcg.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "gbdpcg_create", "gbdpcg_destroy", "gbdpcg_status_string", "gbdpcg_last_hip_error",
-    "gbdpcg_last_hip_error_string", "gbdpcg_set_path", "gbdpcg_choose_path",
+    "gbdpcg_last_hip_error_string", "gbdpcg_set_path", "gbdpcg_choose_path", "gbdpcg_set_symmetric",
+    "gbdpcg_check_symmetric_f32", "gbdpcg_check_symmetric_f64",
     "gbdpcg_pcg_shared_mem_size", "gbdpcg_check_occupancy", "gbdpcg_workspace_bytes",
     "gbdpcg_reserve", "gbdpcg_spmv_f32", "gbdpcg_spmv_f64", "gbdpcg_solve_f32", "gbdpcg_solve_f64",
     "gbdpcg_solve_blocking_f32", "gbdpcg_solve_blocking_f64", "gbdpcg_solve_host_f32",
@@ -110,6 +111,19 @@ class Solver:
 
     def set_path(self, path: int):
         self._check(self.lib.gbdpcg_set_path(self.h, ctypes.c_int(path)), "set_path")
+
+    def set_symmetric(self, on: bool):
+        self._check(self.lib.gbdpcg_set_symmetric(self.h, ctypes.c_int(1 if on else 0)), "set_symmetric")
+
+    def check_symmetric(self, n, N, batch, M, stream=None):
+        """uint8 tensor [batch]: 1 where L_{k+1} == R_k^T bit for bit for every knot."""
+        import torch
+        suf, _ = _suffix(M)
+        flags = torch.empty(batch, dtype=torch.uint8, device=M.device)
+        fn = getattr(self.lib, f"gbdpcg_check_symmetric_{suf}")
+        self._check(fn(self.h, ctypes.c_uint32(n), ctypes.c_uint32(N), ctypes.c_uint32(batch), _p(M), _p(flags),
+                       self._stream(stream)), "check_symmetric")
+        return flags
 
     def choose_path(self, elem_size, n, N, batch) -> int:
         return self.lib.gbdpcg_choose_path(self.h, ctypes.c_uint32(elem_size), ctypes.c_uint32(n),

@@ -13,6 +13,7 @@ using namespace gbdpcg;
 struct gbdpcg_context {
     DeviceInfo dev;
     gbdpcg_path forced = GBDPCG_PATH_AUTO;
+    int symmetric = 0;  // gbdpcg_set_symmetric
     hipError_t last_err = hipSuccess;
     // status words for the blocking entry points (replace the per-call cudaMalloc of interface.cuh:105-108)
     uint32_t *d_iters = nullptr;
@@ -119,6 +120,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
+    a.symmetric = h->symmetric != 0;
     HIP_TRY(h, hipSetDevice(h->dev.device));
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED) {
         HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
@@ -145,6 +147,7 @@ gbdpcg_status spmv_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batc
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     HIP_TRY(h, hipSetDevice(h->dev.device));
     SpmvArgs<T> a{d_M, d_x, d_y, n, N, batch};
+    a.symmetric = h->symmetric != 0;
     HIP_TRY(h, launch_spmv<T>(h->dev, a, stream));
     return GBDPCG_OK;
 }
@@ -350,6 +353,30 @@ gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path)
 {
     if (!h || (int)path < 0 || (int)path > 2) return GBDPCG_ERR_INVALID;
     h->forced = path;
+    return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_set_symmetric(gbdpcg_handle_t h, int assume_symmetric)
+{
+    if (!h) return GBDPCG_ERR_INVALID;
+    h->symmetric = assume_symmetric ? 1 : 0;
+    return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_check_symmetric_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const float *d_M,
+                                         uint8_t *d_flags, void *stream)
+{
+    if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    HIP_TRY(h, launch_check_symmetric<float>(h->dev, n, N, batch, d_M, d_flags, (hipStream_t)stream));
+    return GBDPCG_OK;
+}
+gbdpcg_status gbdpcg_check_symmetric_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const double *d_M,
+                                         uint8_t *d_flags, void *stream)
+{
+    if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    HIP_TRY(h, launch_check_symmetric<double>(h->dev, n, N, batch, d_M, d_flags, (hipStream_t)stream));
     return GBDPCG_OK;
 }
 

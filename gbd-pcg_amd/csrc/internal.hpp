@@ -20,6 +20,7 @@ template <typename T> struct SpmvArgs {
     const T *x;
     T *y;
     uint32_t n, N, batch;
+    bool symmetric = false;
 };
 
 template <typename T> struct PcgArgs {
@@ -34,6 +35,7 @@ template <typename T> struct PcgArgs {
     uint32_t n, N, batch;
     uint32_t *iters;         // [batch]
     uint8_t *max_iter_exit;  // [batch], nullable
+    bool symmetric = false;  // caller asserts L_{k+1} == R_k^T bitwise for S and Pinv (gbdpcg_set_symmetric)
 };
 
 // Widest per-lane vector (in elements) usable for this block size and these base pointers:
@@ -71,6 +73,11 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
 template <typename T> size_t split_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
 template <typename T>
 hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s);
+
+// ---- symcheck.hip : flags[b] = 1 iff L_{k+1} == R_k^T bit for bit for every k of problem b
+template <typename T>
+hipError_t launch_check_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *M,
+                                  uint8_t *flags, hipStream_t s);
 
 // ---- pinv.hip
 template <typename T>

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "bt_device.hpp"
+#include "bt_sym.hpp"
 #include "internal.hpp"
 
 namespace gbdpcg {
@@ -26,16 +27,18 @@ namespace gbdpcg {
 //   yc  N n      SpMV output: S lambda, then upsilon = S p, then r~ = Pinv r
 //   lam N n      lambda
 //   red 2*WAVES  per-wave partials of the two inner products
+//   zc  N n      (symmetric streaming only) the transposed products R_{k-1}^T x_{k-1}, added into yc
 template <typename T> struct FusedCarve {
-    uint32_t xa, xb, yc, lam, red, total;
-    __host__ __device__ FusedCarve(uint32_t n, uint32_t N, uint32_t waves) {
+    uint32_t xa, xb, yc, lam, red, zc, total;
+    __host__ __device__ FusedCarve(uint32_t n, uint32_t N, uint32_t waves, bool sym = false) {
         const uint32_t padded = align16<T>((N + 2) * n), plain = align16<T>(N * n);
         xa = 0;
         xb = xa + padded;
         yc = xb + padded;
         lam = yc + plain;
         red = lam + plain;
-        total = red + align16<T>(2 * waves);
+        zc = red + align16<T>(2 * waves);
+        total = zc + (sym ? plain : 0u);
     }
 };
 
@@ -74,7 +77,9 @@ __device__ __forceinline__ T wg_sum(T part, T *red, uint32_t lane, uint32_t wave
     return tot;
 }
 
-template <typename T, int NCT, int V, int WAVES>
+// SYM: both matrices are symmetric block-tridiagonal (L_{k+1} == R_k^T) and are streamed through
+// SymStream (bt_sym.hpp): [D_k | R_k] only, 2/3 of the bytes.
+template <typename T, int NCT, int V, int WAVES, bool SYM>
 __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -86,12 +91,15 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     const uint32_t len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps row bases in SGPRs
-    const FusedCarve<T> cv(n, N, WAVES);
+    const FusedCarve<T> cv(n, N, WAVES, SYM);
     T *xa = smem + cv.xa, *xb = smem + cv.xb, *yc = smem + cv.yc, *lam = smem + cv.lam;
     T *red0 = smem + cv.red, *red1 = red0 + WAVES;
+    T *zc = smem + cv.zc;
     const LaneMap<NCT, V> m(n, lane);
     const StreamCtx<T, NCT, V> cx(m, lane);
     RowStream<T, NCT, V> rs;
+    const SymCtx<T, NCT> scx(lane);
+    SymStream<T, NCT> ss;
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
@@ -101,10 +109,11 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
         T *lambda = a.lambda + (size_t)prob * len;
 
         // first matrix loads go out before anything else touches memory
-        rs.prime(S, wave, N, WAVES, cx, n);
+        if constexpr (SYM) ss.prime(S, wave, N, WAVES, scx); else rs.prime(S, wave, N, WAVES, cx, n);
         for (uint32_t i = tid; i < n; i += THREADS) {
             xa[i] = T(0); xa[n + len + i] = T(0);
             xb[i] = T(0); xb[n + len + i] = T(0);
+            if constexpr (SYM) zc[i] = T(0);  // row 0 has no block-row above it
         }
         for (uint32_t i = tid; i < len; i += THREADS) {
             const T l = lambda[i];
@@ -129,7 +138,10 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
             const bool precond = phase & 1u;
             const T *X = precond ? xb : xa;
 #ifndef GBDPCG_EARLY_PRIME
-            if (phase > 0 && !(precond && !P)) rs.prime(precond ? P : S, wave, N, WAVES, cx, n);
+            if (phase > 0 && !(precond && !P)) {
+                if constexpr (SYM) ss.prime(precond ? P : S, wave, N, WAVES, scx);
+                else rs.prime(precond ? P : S, wave, N, WAVES, cx, n);
+            }
 #endif
             T part = T(0);
             if (precond && !P) {  // identity preconditioner: r~ = r (the primed S units stay in flight)
@@ -137,6 +149,24 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
                     const T rv = xb[n + i];
                     yc[i] = rv;
                     part = fma_t(rv, rv, part);
+                }
+            } else if constexpr (SYM) {
+                ss.run(X + n, N, scx,
+                       [&](uint32_t k, T a0, T a1) __attribute__((always_inline)) {
+                           if (scx.g == 0 && scx.act) {
+                               yc[k * n + scx.rp * 2] = a0;
+                               yc[k * n + scx.rp * 2 + 1] = a1;
+                           }
+                       },
+                       [&](uint32_t k, uint32_t c, T t) __attribute__((always_inline)) {
+                           if (scx.rp == 0) zc[(k + 1) * n + c - n] = t;
+                       });
+                __syncthreads();
+                // y = (D x_k + R x_{k+1}) + R_{k-1}^T x_{k-1}; the inner product needs the complete y
+                for (uint32_t i = tid; i < len; i += THREADS) {
+                    const T yv = yc[i] + zc[i];
+                    yc[i] = yv;
+                    part = fma_t(yv, X[n + i], part);
                 }
             } else {
                 part = wg_spmv_dot<T, NCT, V>(rs, X, yc, X, m, cx, n, N, lane);
@@ -205,12 +235,12 @@ template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_
     return fused_lds_bytes<T>(n, N, 16) <= dev.lds_per_wg_max;
 }
 
-template <typename T, int NCT, int V, int WAVES>
+template <typename T, int NCT, int V, int WAVES, bool SYM = false>
 static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
 {
-    const size_t lds = fused_lds_bytes<T>(a.n, a.N, WAVES);
+    const size_t lds = (size_t)FusedCarve<T>(a.n, a.N, WAVES, SYM).total * sizeof(T);
     if (lds > dev.lds_per_wg_max) return hipErrorInvalidValue;
-    auto kern = pcg_fused_kernel<T, NCT, V, WAVES>;
+    auto kern = pcg_fused_kernel<T, NCT, V, WAVES, SYM>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -248,6 +278,17 @@ static hipError_t launch_fused_v(const DeviceInfo &dev, const PcgArgs<T> &a, hip
     int waves = a.batch < (uint32_t)dev.num_cus ? 16 : 8;
     if (forced == 4 || forced == 8 || forced == 16) waves = forced;
     while (waves > 4 && fused_lds_bytes<T>(a.n, a.N, waves) > dev.lds_per_wg_max) waves /= 2;
+    if constexpr (SymGeom<T, NCT>::OK) {
+        const uintptr_t al = 2 * sizeof(T);
+        const bool aligned = reinterpret_cast<uintptr_t>(a.S) % al == 0 &&
+                             (!a.Pinv || reinterpret_cast<uintptr_t>(a.Pinv) % al == 0);
+        if (a.symmetric && aligned && waves != 4) {
+            if (waves == 16 && FusedCarve<T>(a.n, a.N, 16, true).total * sizeof(T) <= dev.lds_per_wg_max)
+                return launch_fused_w<T, NCT, V, 16, true>(dev, a, s);
+            if (FusedCarve<T>(a.n, a.N, 8, true).total * sizeof(T) <= dev.lds_per_wg_max)
+                return launch_fused_w<T, NCT, V, 8, true>(dev, a, s);
+        }
+    }
     switch (waves) {
     case 16: return launch_fused_w<T, NCT, V, 16>(dev, a, s);
     case 8: return launch_fused_w<T, NCT, V, 8>(dev, a, s);

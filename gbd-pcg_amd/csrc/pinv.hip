@@ -55,9 +55,12 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_kernel(uint32_t n, uin
             __syncthreads();
         }
     }
+    // D_k^-1 of a symmetric D_k is symmetric in exact arithmetic but not bit for bit after the
+    // elimination; the upper triangle is mirrored so that the stair blocks built from it come out
+    // exactly symmetric (L_{k+1} == R_k^T) whenever S is -- what gbdpcg_set_symmetric relies on.
     for (uint32_t i = tid; i < n * n; i += kPinvThreads) {
         const uint32_t c = i / n, r = i - c * n;
-        out[(size_t)n * n + i] = tab[r * w + n + c];
+        out[(size_t)n * n + i] = r <= c ? tab[r * w + n + c] : tab[c * w + n + r];
         out[i] = T(0);
         out[(size_t)2 * n * n + i] = T(0);
     }
@@ -78,13 +81,25 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, ui
     const size_t blk = (size_t)blockIdx.x * 3 * n * n;
     const uint32_t nn = n * n;
 
+    // Right slot:  R'_k     = -(D_k^-1 R_k) D_{k+1}^-1.
+    // Left slot :  L'_k     = -D_k^-1 L_k D_{k-1}^-1, evaluated as the TRANSPOSE of
+    //              X = -(D_{k-1}^-1 L_k^T) D_k^-1  -- the same operation sequence the right slot of
+    //              knot k-1 runs on (D_{k-1}^-1, R_{k-1}, D_k^-1).  With symmetric D^-1 blocks the two are
+    //              equal as matrices for any S, and bit for bit each other's transpose when L_k == R_{k-1}^T.
     for (int side = 0; side < 2; ++side) {  // 0: left slot (needs k-1), 1: right slot (needs k+1)
         if ((side == 0 && k == 0) || (side == 1 && k == N - 1)) continue;
         const size_t nb = side == 0 ? blk - (size_t)3 * nn : blk + (size_t)3 * nn;
         for (uint32_t i = tid; i < nn; i += kPinvThreads) {
-            A[i] = Pinv[blk + nn + i];
-            B[i] = S[blk + (side == 0 ? 0 : 2 * (size_t)nn) + i];
-            C[i] = Pinv[nb + nn + i];
+            const uint32_t c = i / n, r = i - c * n;
+            if (side == 1) {
+                A[i] = Pinv[blk + nn + i];            // D_k^-1
+                B[i] = S[blk + 2 * (size_t)nn + i];   // R_k
+                C[i] = Pinv[nb + nn + i];             // D_{k+1}^-1
+            } else {
+                A[i] = Pinv[nb + nn + i];             // D_{k-1}^-1
+                B[i] = S[blk + (size_t)r * n + c];    // L_k^T : element (r,c) = L_k(c,r)
+                C[i] = Pinv[blk + nn + i];            // D_k^-1
+            }
         }
         __syncthreads();
         for (uint32_t i = tid; i < nn; i += kPinvThreads) {
@@ -98,7 +113,8 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, ui
             const uint32_t c = i / n, r = i - c * n;
             T acc = T(0);
             for (uint32_t q = 0; q < n; ++q) acc = fma_t(W[q * n + r], C[c * n + q], acc);
-            Pinv[blk + (side == 0 ? 0 : 2 * (size_t)nn) + i] = -acc;
+            if (side == 1) Pinv[blk + 2 * (size_t)nn + i] = -acc;                  // R'_k(r,c)
+            else Pinv[blk + (size_t)r * n + c] = -acc;                             // L'_k(c,r) = X(r,c)
         }
         __syncthreads();
     }

@@ -330,3 +330,54 @@ def test_full_size_config3_properties(solver):
     iters2, _ = solver.solve(n, N, B, g["S"], g["Pinv"], g["gamma"], lam, tol=1e-6, max_iter=50)
     torch.cuda.synchronize()
     assert int(iters2.max()) == 1
+
+
+# ------------------------------------------------------------------------------------- symmetric streaming
+def _symmetrize_pinv(n, N, P):
+    """Pinv with L_{k+1} := R_k^T exactly (the numpy stair blocks are each other's transpose only up to rounding)."""
+    L, D, R = synth.unpack_bt(n, N, P)
+    L = L.copy()
+    L[..., 1:, :, :] = np.swapaxes(R[..., :-1, :, :], -1, -2)
+    return synth.pack_bt(L, D, R)
+
+
+def test_check_symmetric(solver):
+    n, N, B = 14, 20, 5
+    d = synth.gen_numpy(n, N, seed=61, batch=B, dtype=np.float32)
+    S = d["S"].copy()
+    assert solver.check_symmetric(n, N, B, dev(S)).cpu().numpy().tolist() == [1] * B   # generator: R_k = L_{k+1}^T exactly
+    S[3, (7 * 3 + 2) * n * n + 5] += 1e-3                                                  # one element of R_7 of problem 3
+    assert solver.check_symmetric(n, N, B, dev(S)).cpu().numpy().tolist() == [1, 1, 1, 0, 1]
+    P = _symmetrize_pinv(n, N, d["Pinv"])
+    assert solver.check_symmetric(n, N, B, dev(P)).cpu().numpy().tolist() == [1] * B
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_form_pinv_is_exactly_symmetric(solver, dtype):
+    n, N, B = 14, 12, 4
+    d = synth.gen_numpy(n, N, seed=62, batch=B, dtype=dtype)
+    P = solver.form_pinv(n, N, B, dev(d["S"]), binding.PINV_STAIR)
+    assert solver.check_symmetric(n, N, B, P).cpu().numpy().tolist() == [1] * B
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,N,B", [(14, 128, 8), (14, 100, 300), (14, 73, 2), (12, 40, 6), (16, 33, 5), (8, 50, 3)])
+def test_symmetric_streaming_solve(solver, orc, dtype, n, N, B):
+    """gbdpcg_set_symmetric: only [D|R] is read and L_{k+1} x_k is formed as R_k^T x_k.  On exactly
+    symmetric storage the oracle (which reads L like the reference) must be matched as usual."""
+    base = min(B, 8)
+    d = synth.gen_numpy(n, N, seed=500 + n + N, batch=base, dtype=dtype)
+    idx = np.arange(B) % base
+    S = d["S"][idx]
+    P = _symmetrize_pinv(n, N, d["Pinv"])[idx]
+    g = (d["gamma"][idx] * (1.0 + 0.01 * np.arange(B))[:, None]).astype(dtype)
+    solver.set_symmetric(True)
+    try:
+        out = gpu_solve(solver, n, N, B, S, P, g, tol=1e-6, max_iter=60, path=binding.PATH_FUSED)
+    finally:
+        solver.set_symmetric(False)
+    ob = orc.pcg_batch(n, N, B, S, P, g, tol=1e-6, max_iter=60)
+    assert np.array_equal(out["iters"], ob["iters"]) and not out["max_iter_exit"].any()
+    tol = F64_TOL if dtype == np.float64 else F32_TOL
+    for b in range(0, B, max(1, B // 8)):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol
