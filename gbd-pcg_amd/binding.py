@@ -112,8 +112,9 @@ class Solver:
     def set_path(self, path: int):
         self._check(self.lib.gbdpcg_set_path(self.h, ctypes.c_int(path)), "set_path")
 
-    def set_symmetric(self, on: bool):
-        self._check(self.lib.gbdpcg_set_symmetric(self.h, ctypes.c_int(1 if on else 0)), "set_symmetric")
+    def set_symmetric(self, mode):
+        """0 / False: never, 1 / True: assume, 2: test on the device before every solve (the default)."""
+        self._check(self.lib.gbdpcg_set_symmetric(self.h, ctypes.c_int(int(mode))), "set_symmetric")
 
     def check_symmetric(self, n, N, batch, M, stream=None):
         """uint8 tensor [batch]: 1 where L_{k+1} == R_k^T bit for bit for every knot."""

@@ -13,7 +13,9 @@ using namespace gbdpcg;
 struct gbdpcg_context {
     DeviceInfo dev;
     gbdpcg_path forced = GBDPCG_PATH_AUTO;
-    int symmetric = 0;  // gbdpcg_set_symmetric
+    int symmetric = 2;  // gbdpcg_set_symmetric: 0 never, 1 assume, 2 check on the device (default)
+    uint8_t *sym_flags = nullptr;  // [sym_cap] per-problem result of the check
+    size_t sym_cap = 0;
     hipError_t last_err = hipSuccess;
     // status words for the blocking entry points (replace the per-call cudaMalloc of interface.cuh:105-108)
     uint32_t *d_iters = nullptr;
@@ -112,6 +114,25 @@ gbdpcg_status ensure_ws(gbdpcg_handle_t h, size_t bytes)
     return GBDPCG_OK;
 }
 
+gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
+{
+    if (batch <= h->sym_cap) return GBDPCG_OK;
+    if (h->sym_flags) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipFree(h->sym_flags));
+        h->sym_flags = nullptr;
+        h->sym_cap = 0;
+    }
+    const size_t cap = (batch + 255) / 256 * 256;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->sym_flags), cap);
+    if (e != hipSuccess) {
+        h->last_err = e;
+        return GBDPCG_ERR_ALLOC;
+    }
+    h->sym_cap = cap;
+    return GBDPCG_OK;
+}
+
 template <typename T>
 gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S, const T *d_Pinv,
                          const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
@@ -120,10 +141,33 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
-    a.symmetric = h->symmetric != 0;
     HIP_TRY(h, hipSetDevice(h->dev.device));
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED) {
-        HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+        const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
+        if (has_sym && h->symmetric == 2) {
+            // AUTO: test L_{k+1} == R_k^T on the device (S, then Pinv and-ed in), then launch BOTH kernels:
+            // the symmetric one takes the problems that passed, the general one the rest.  No host
+            // round trip, so the whole thing stays asynchronous and graph-capturable.
+            if (batch > h->sym_cap) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                    return GBDPCG_ERR_ALLOC;
+                gbdpcg_status st = ensure_sym_flags(h, batch);
+                if (st != GBDPCG_OK) return st;
+            }
+            HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_S, h->sym_flags, false, stream));
+            HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_Pinv, h->sym_flags, true, stream));
+            a.sel = h->sym_flags;
+            a.symmetric = true;
+            a.want = 1;
+            HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+            a.symmetric = false;
+            a.want = 0;
+            HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+        } else {
+            a.symmetric = has_sym && h->symmetric == 1;
+            HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+        }
     } else {
         const size_t need = split_workspace_bytes<T>(n, N, batch);
         if (need > h->ws_bytes) {
@@ -147,7 +191,7 @@ gbdpcg_status spmv_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batc
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     HIP_TRY(h, hipSetDevice(h->dev.device));
     SpmvArgs<T> a{d_M, d_x, d_y, n, N, batch};
-    a.symmetric = h->symmetric != 0;
+    a.symmetric = h->symmetric == 1;  // a check would cost as much as the product itself
     HIP_TRY(h, launch_spmv<T>(h->dev, a, stream));
     return GBDPCG_OK;
 }
@@ -218,6 +262,9 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     HIP_TRY(h, hipSetDevice(h->dev.device));
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
+        if (st != GBDPCG_OK) return st;
+    } else if (h->symmetric == 2) {
+        gbdpcg_status st = ensure_sym_flags(h, batch);
         if (st != GBDPCG_OK) return st;
     }
     hipStream_t cs = nullptr;
@@ -322,6 +369,7 @@ gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
     if (!h) return GBDPCG_ERR_INVALID;
     (void)hipSetDevice(h->dev.device);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->sym_flags) (void)hipFree(h->sym_flags);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->h_iters) (void)hipHostFree(h->h_iters);
     delete h;
@@ -356,10 +404,10 @@ gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path)
     return GBDPCG_OK;
 }
 
-gbdpcg_status gbdpcg_set_symmetric(gbdpcg_handle_t h, int assume_symmetric)
+gbdpcg_status gbdpcg_set_symmetric(gbdpcg_handle_t h, int mode)
 {
-    if (!h) return GBDPCG_ERR_INVALID;
-    h->symmetric = assume_symmetric ? 1 : 0;
+    if (!h || mode < 0 || mode > 2) return GBDPCG_ERR_INVALID;
+    h->symmetric = mode;
     return GBDPCG_OK;
 }
 
@@ -368,7 +416,7 @@ gbdpcg_status gbdpcg_check_symmetric_f32(gbdpcg_handle_t h, uint32_t n, uint32_t
 {
     if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev.device));
-    HIP_TRY(h, launch_check_symmetric<float>(h->dev, n, N, batch, d_M, d_flags, (hipStream_t)stream));
+    HIP_TRY(h, launch_check_symmetric<float>(h->dev, n, N, batch, d_M, d_flags, false, (hipStream_t)stream));
     return GBDPCG_OK;
 }
 gbdpcg_status gbdpcg_check_symmetric_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const double *d_M,
@@ -376,7 +424,7 @@ gbdpcg_status gbdpcg_check_symmetric_f64(gbdpcg_handle_t h, uint32_t n, uint32_t
 {
     if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev.device));
-    HIP_TRY(h, launch_check_symmetric<double>(h->dev, n, N, batch, d_M, d_flags, (hipStream_t)stream));
+    HIP_TRY(h, launch_check_symmetric<double>(h->dev, n, N, batch, d_M, d_flags, false, (hipStream_t)stream));
     return GBDPCG_OK;
 }
 

@@ -35,7 +35,11 @@ template <typename T> struct PcgArgs {
     uint32_t n, N, batch;
     uint32_t *iters;         // [batch]
     uint8_t *max_iter_exit;  // [batch], nullable
-    bool symmetric = false;  // caller asserts L_{k+1} == R_k^T bitwise for S and Pinv (gbdpcg_set_symmetric)
+    bool symmetric = false;  // stream [D|R] only: caller's assertion, or per problem where sel says so
+    // Per-problem kernel selection (symmetric AUTO mode): a launch handles problem b only when
+    // sel[b] == want.  sel == nullptr: every problem.
+    const uint8_t *sel = nullptr;
+    uint8_t want = 0;
 };
 
 // Widest per-lane vector (in elements) usable for this block size and these base pointers:
@@ -66,6 +70,7 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
 
 // ---- pcg_resident.hip : both matrices register-resident, one 8-wave workgroup per problem.
 // Returns false when the shape is not eligible (then nothing was launched).
+template <typename T> bool resident_shape(uint32_t n, uint32_t N);  // shape handled by the resident kernel
 template <typename T>
 bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
 
@@ -75,9 +80,12 @@ template <typename T>
 hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s);
 
 // ---- symcheck.hip : flags[b] = 1 iff L_{k+1} == R_k^T bit for bit for every k of problem b
+// and_into: flags[b] &= result instead of flags[b] = result (second matrix of a pair).
 template <typename T>
 hipError_t launch_check_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *M,
-                                  uint8_t *flags, hipStream_t s);
+                                  uint8_t *flags, bool and_into, hipStream_t s);
+// Does launch_pcg_fused have a symmetric-streaming kernel for this shape (and would it be used)?
+template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
 
 // ---- pinv.hip
 template <typename T>

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
+        if (a.sel && a.sel[prob] != a.want) continue;  // this launch is not the one that owns the problem
         const T *S = a.S + prob * mstride;
         const T *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;
         const T *gamma = a.gamma + (size_t)prob * len;
@@ -225,6 +226,18 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     }
 }
 
+template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (batch < (uint32_t)dev.num_cus) return false;  // small batches: not worth the symmetry check
+    if (resident_shape<T>(n, N)) return false;         // register-resident kernel reads each matrix once anyway
+    bool ok = false;
+#define GBDPCG_CASE(NN) \
+    if (n == NN) ok = SymGeom<T, NN>::OK && best_v<T, NN>() >= 2;
+    GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
+    return ok && FusedCarve<T>(n, N, 8, true).total * sizeof(T) <= dev.lds_per_wg_max;
+}
+
 template <typename T> size_t fused_lds_bytes(uint32_t n, uint32_t N, uint32_t waves)
 {
     return (size_t)FusedCarve<T>(n, N, waves).total * sizeof(T);
@@ -326,6 +339,8 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
     return launch_fused_n<T, 0>(dev, a, V, s);
 }
 
+template bool fused_has_symmetric<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
+template bool fused_has_symmetric<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
 template size_t fused_lds_bytes<float>(uint32_t, uint32_t, uint32_t);
 template size_t fused_lds_bytes<double>(uint32_t, uint32_t, uint32_t);
 template bool fused_fits<float>(const DeviceInfo &, uint32_t, uint32_t);

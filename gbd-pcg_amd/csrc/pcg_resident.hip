@@ -235,15 +235,20 @@ __global__ __launch_bounds__(512) void pcg_resident_kernel(PcgArgs<T> a)
 // Taken whenever the shape fits (n = 14, fp32, N <= 72): the matrices are then read once per solve
 // instead of once per iteration.  The fp64 map (1 row per lane, N <= 32) is written but disabled: 168
 // matrix VGPRs plus the fp64 working set spill.  GBDPCG_NO_RESIDENT disables the path (tuning runs).
+template <typename T> bool resident_shape(uint32_t n, uint32_t N)
+{
+    static const bool off = getenv("GBDPCG_NO_RESIDENT") != nullptr;
+    if (off || n != 14 || sizeof(T) == 8) return false;
+    return N <= DenseGeom<T, 14, (sizeof(T) == 4 ? 2 : 1)>::MAX_KNOTS;
+}
+
 template <typename T>
 bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
 {
-    static const bool off = getenv("GBDPCG_NO_RESIDENT") != nullptr;
-    if (off || a.n != 14 || sizeof(T) == 8) return false;
+    if (!resident_shape<T>(a.n, a.N)) return false;
     constexpr int RV = sizeof(T) == 4 ? 2 : 1;
     using Dg = DenseGeom<T, 14, RV>;
     static_assert(2 * Dg::REGS <= 176, "resident matrices must leave registers for the solve");
-    if (a.N > Dg::MAX_KNOTS) return false;
     const uintptr_t al = RV * sizeof(T);
     if ((reinterpret_cast<uintptr_t>(a.S) % al) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % al)) return false;
     const size_t lds = ((size_t)2 * align16<T>((a.N + 2) * a.n) + 2 * align16<T>(Dg::WAVES)) * sizeof(T);
@@ -254,6 +259,8 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
     return true;
 }
 
+template bool resident_shape<float>(uint32_t, uint32_t);
+template bool resident_shape<double>(uint32_t, uint32_t);
 template bool launch_pcg_resident<float>(const DeviceInfo &, const PcgArgs<float> &, hipStream_t, hipError_t *);
 template bool launch_pcg_resident<double>(const DeviceInfo &, const PcgArgs<double> &, hipStream_t, hipError_t *);
 

@@ -371,13 +371,69 @@ def test_symmetric_streaming_solve(solver, orc, dtype, n, N, B):
     S = d["S"][idx]
     P = _symmetrize_pinv(n, N, d["Pinv"])[idx]
     g = (d["gamma"][idx] * (1.0 + 0.01 * np.arange(B))[:, None]).astype(dtype)
-    solver.set_symmetric(True)
+    solver.set_symmetric(1)      # assume: no device check, symmetric kernel for every problem
     try:
         out = gpu_solve(solver, n, N, B, S, P, g, tol=1e-6, max_iter=60, path=binding.PATH_FUSED)
     finally:
-        solver.set_symmetric(False)
+        solver.set_symmetric(2)  # back to the default (check on the device)
     ob = orc.pcg_batch(n, N, B, S, P, g, tol=1e-6, max_iter=60)
     assert np.array_equal(out["iters"], ob["iters"]) and not out["max_iter_exit"].any()
     tol = F64_TOL if dtype == np.float64 else F32_TOL
     for b in range(0, B, max(1, B // 8)):
         assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_symmetric_auto_mixed_batch(solver, orc, dtype, mode):
+    """Default mode 2: the symmetry relation is tested per problem on the device; a batch that mixes
+    exactly symmetric problems with ones whose L blocks were perturbed (so that L_{k+1} != R_k^T, still a
+    valid general block-tridiagonal input) must match the oracle on every problem -- symmetric ones through
+    the [D|R] kernel, the others through the general one.  Mode 0 (never) is the control."""
+    n, N, B = 14, 100, 300
+    d = synth.gen_numpy(n, N, seed=77, batch=8, dtype=dtype)
+    idx = np.arange(B) % 8
+    S = d["S"][idx].copy()
+    P = _symmetrize_pinv(n, N, d["Pinv"])[idx].copy()
+    g = (d["gamma"][idx] * (1.0 + 0.01 * np.arange(B))[:, None]).astype(dtype)
+    # break the relation in every third problem: scale one L block of S, one of Pinv in others
+    for b in range(0, B, 3):
+        S[b, (5 * 3 + 0) * n * n:(5 * 3 + 1) * n * n] *= 1.001
+    for b in range(1, B, 7):
+        P[b, (9 * 3 + 0) * n * n:(9 * 3 + 1) * n * n] *= 0.999
+    flags = (solver.check_symmetric(n, N, B, dev(S)) & solver.check_symmetric(n, N, B, dev(P))).cpu().numpy()
+    assert 0 < flags.sum() < B
+    solver.set_symmetric(mode)
+    try:
+        out = gpu_solve(solver, n, N, B, S, P, g, tol=1e-6, max_iter=60, path=binding.PATH_FUSED)
+    finally:
+        solver.set_symmetric(2)
+    ob = orc.pcg_batch(n, N, B, S, P, g, tol=1e-6, max_iter=60, nthreads=8)
+    assert np.array_equal(out["iters"], ob["iters"]) and not out["max_iter_exit"].any()
+    tol = F64_TOL if dtype == np.float64 else F32_TOL
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol, (b, flags[b])
+
+
+def test_symmetric_auto_in_graph(solver, orc):
+    """The check + two-kernel dispatch of mode 2 is capturable: graph replays equal the eager solve."""
+    n, N, B = 14, 90, 260
+    d = synth.gen_numpy(n, N, seed=78, batch=4, dtype=np.float32)
+    idx = np.arange(B) % 4
+    S, P, g = d["S"][idx].copy(), _symmetrize_pinv(n, N, d["Pinv"])[idx].copy(), d["gamma"][idx].copy()
+    S[1::2, (3 * 3) * n * n:(3 * 3 + 1) * n * n] *= 1.01   # odd problems: not symmetric
+    eager = gpu_solve(solver, n, N, B, S, P, g, tol=1e-6, max_iter=40, path=binding.PATH_FUSED)
+    dS, dP, dg = dev(S), dev(P), dev(g)
+    lam = torch.zeros_like(dg)
+    iters = torch.zeros(B, dtype=torch.int32, device="cuda")
+    flags = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    solver.set_path(binding.PATH_FUSED)
+    gr = solver.graph_solve(n, N, B, dS, dP, dg, lam, None, None, 1e-6, 40, iters, flags)
+    solver.set_path(binding.PATH_AUTO)
+    for _ in range(2):
+        lam.zero_()
+        gr.launch()
+        torch.cuda.synchronize()
+        assert np.array_equal(lam.cpu().numpy().reshape(B, -1), eager["lambda_"])
+        assert np.array_equal(iters.cpu().numpy(), eager["iters"])
+    gr.close()
