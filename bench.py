@@ -195,6 +195,22 @@ def main():
         rounds.append(sum(e0.elapsed_time(e1) for e0, e1 in evs[2:]) / (SP_LAUNCHES - 2))
     sp_ms = sorted(rounds)[1]
     sp_gbps = spmv_bytes_per_launch(n, N, B, 4) / (sp_ms * 1e-3) / 1e9
+    # the same product with gbdpcg_set_symmetric(1): only [D|R] is read (a device check would cost as
+    # much as the product, so the standalone SpMV uses the symmetric kernel only on the caller's word)
+    solver.set_symmetric(1)
+    rounds = []
+    for _ in range(3):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SP_LAUNCHES)]
+        torch.cuda.synchronize()
+        for k, (e0, e1) in enumerate(evs):
+            e0.record(stream)
+            solver.spmv(n, N, B, S if k % 2 == 0 else P, x, y)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        rounds.append(sum(e0.elapsed_time(e1) for e0, e1 in evs[2:]) / (SP_LAUNCHES - 2))
+    solver.set_symmetric(2)
+    sps_ms = sorted(rounds)[1]
+    sps_gbps = spmv_bytes_per_launch(n, N, B, 4) / (sps_ms * 1e-3) / 1e9
 
     def time_mode(mode, reps):
         """Per-replay HIP-event time of the solve graph built under gbdpcg_set_symmetric(mode)."""
@@ -264,6 +280,10 @@ def main():
                      "frac_of_cold_read_ceiling": sp_gbps / HBM_COLD_READ_GBPS,
                      "traffic": pmc_traffic("spmv_kernel<float,14"),
                      "algorithmic_bytes_per_launch": spmv_bytes_per_launch(n, N, B, 4), "kernel_ms": sp_ms},
+            "spmv_symmetric": {"kernel": "spmv_sym_kernel<float,14,4> (gbdpcg_set_symmetric(1): reads [D|R] only)",
+                               "achieved": sps_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sps_gbps / HBM_PEAK_GBPS,
+                               "traffic": pmc_traffic("spmv_sym_kernel<float,14"), "kernel_ms": sps_ms,
+                               "bytes_streamed_per_launch": B * ((2 * N - 1) * n * n + 2 * n * N) * 4},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, N, iters)

@@ -437,3 +437,26 @@ def test_symmetric_auto_in_graph(solver, orc):
         assert np.array_equal(lam.cpu().numpy().reshape(B, -1), eager["lambda_"])
         assert np.array_equal(iters.cpu().numpy(), eager["iters"])
     gr.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,N,B", [(14, 128, 8), (14, 1, 3), (14, 2, 3), (14, 37, 5), (14, 300, 2), (12, 40, 6), (16, 33, 5), (8, 50, 3)])
+def test_symmetric_spmv(solver, orc, dtype, n, N, B):
+    """gbdpcg_set_symmetric(1) on the standalone SpMV: [D|R] only, chunk seams included (N = 300 is
+    split over several workgroups per problem).  L blocks are poisoned with NaN: they must not be read."""
+    d = synth.gen_numpy(n, N, seed=600 + n + N, batch=B, dtype=dtype)
+    x = np.stack([synth.normals(700 + b, 0, n * N) for b in range(B)]).astype(dtype)
+    S = d["S"].copy()
+    want = np.stack([orc.dense_from_bt(n, N, S[b]) @ x[b].astype(np.float64) for b in range(B)])
+    Sp = S.reshape(B, N, 3, n * n).copy()
+    Sp[:, :, 0, :] = np.nan                      # every L block
+    solver.set_symmetric(1)
+    try:
+        y = solver.spmv(n, N, B, dev(Sp.reshape(B, -1)), dev(x))
+        torch.cuda.synchronize()
+    finally:
+        solver.set_symmetric(2)
+    y = y.cpu().numpy()
+    tol = 1e-13 if dtype == np.float64 else F32_TOL
+    for b in range(B):
+        assert relerr(y[b], want[b]) < tol
