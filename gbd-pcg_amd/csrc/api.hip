@@ -344,10 +344,10 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     if (!h) return GBDPCG_ERR_ALLOC;
     h->dev.device = device;
     h->dev.num_cus = prop.multiProcessorCount;
+    // gfx950: 160 KiB of LDS per CU, and one workgroup may take all of it (hipDeviceProp_t reports the
+    // 64 KiB default window; larger dynamic sizes are opted into per kernel with hipFuncSetAttribute)
     h->dev.lds_per_cu = 160 * 1024;
-    h->dev.lds_per_wg_max = prop.sharedMemPerBlock > 0 && prop.sharedMemPerBlock < 160 * 1024
-                                ? (size_t)160 * 1024
-                                : (size_t)160 * 1024;
+    h->dev.lds_per_wg_max = 160 * 1024;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
     if (e == hipSuccess) {

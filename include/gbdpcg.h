@@ -66,8 +66,11 @@ typedef enum gbdpcg_pinv_kind {
 
 /* ---- lifetime ------------------------------------------------------------------------ */
 
-/* One handle per host thread.  `device` is a HIP ordinal.  Allocates a few status words and
- * pinned host words; replaces the per-call cudaMalloc/cudaFree of interface.cuh:105-108,140-141. */
+/* One handle per host thread AND per stream of concurrent work: a handle owns device scratch (status
+ * words, the split path's workspace, the per-problem symmetry flags) that every solve and every graph
+ * created through it uses, so two solves issued through the same handle must not overlap in time
+ * (same stream, or otherwise ordered).  `device` is a HIP ordinal.  Replaces the per-call
+ * cudaMalloc/cudaFree of interface.cuh:105-108,140-141. */
 gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device);
 gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h);
 
