@@ -460,3 +460,26 @@ def test_symmetric_spmv(solver, orc, dtype, n, N, B):
     tol = 1e-13 if dtype == np.float64 else F32_TOL
     for b in range(B):
         assert relerr(y[b], want[b]) < tol
+
+
+@pytest.mark.parametrize("mode", [2, 0])
+def test_full_config3_batch_against_oracle(solver, orc, mode):
+    """BASELINE config 3 in full -- n=14, N=128, fp32, all 1024 problems (seeds 1234+i) -- against the
+    fp32 oracle problem by problem: equal iteration counts and lambda within 1e-6 norm-wise, through the
+    default path (device symmetry check + [D|R] streaming; Pinv symmetrised exactly) and with mode 0."""
+    n, N, B = 14, 128, 1024
+    d = synth.gen_numpy(n, N, seed=1234, batch=B, dtype=np.float32)
+    P = _symmetrize_pinv(n, N, d["Pinv"])
+    if mode == 2:
+        fl = (solver.check_symmetric(n, N, B, dev(d["S"])) & solver.check_symmetric(n, N, B, dev(P))).cpu().numpy()
+        assert fl.all()
+    solver.set_symmetric(mode)
+    try:
+        out = gpu_solve(solver, n, N, B, d["S"], P, d["gamma"], tol=1e-6, max_iter=50)
+    finally:
+        solver.set_symmetric(2)
+    ob = orc.pcg_batch(n, N, B, d["S"], P, d["gamma"], tol=1e-6, max_iter=50, nthreads=8)
+    assert np.array_equal(out["iters"], ob["iters"]) and not out["max_iter_exit"].any()
+    num = np.linalg.norm(out["lambda_"].astype(np.float64) - ob["lambda_"], axis=1)
+    den = np.linalg.norm(ob["lambda_"].astype(np.float64), axis=1)
+    assert (num / den).max() < F32_TOL
