@@ -113,31 +113,58 @@ template <typename T, int NCT> struct SymStream {
     //   main result  y_k[2rp], y_k[2rp+1]  -> on_main(k, a0, a1)   valid in lanes g == 0 && act
     //   transposed   (R_k^T x_k)[c - n]    -> on_trans(k, c, t)    valid in lanes rp == 0, for the
     //                                         columns c >= n this lane's group owns (k < N-1 only)
+    // The kernel is instruction-issue bound (SQ_ACTIVE_INST_ANY ~ kernel cycles per SIMD), so the
+    // common case carries no per-element masking: the idle lane of each group (rp = 7 for n = 14) is
+    // neutralised once through its x operand, only the ragged last step masks its out-of-row lanes,
+    // and the last block-row (whose R block must not be used) takes a separate, masked copy of the loop.
+    template <bool LASTROW>
+    __device__ __forceinline__ void row_products(const Unit &u, const T *xk, const SymCtx<T, NCT> &cx, T &a0, T &a1,
+                                                 T (&t)[Sg::STEPS]) {
+        constexpr uint32_t n = Sg::N_;
+        using P2 = typename VecOf<T, 2>::type;
+        P2 own = *reinterpret_cast<const P2 *>(xk + (cx.act ? cx.rp * 2 : 0u));
+        own.x = cx.act ? own.x : T(0);  // idle lanes hold junk matrix elements: their row operand is 0 ...
+        own.y = cx.act ? own.y : T(0);
+        a0 = T(0);
+        a1 = T(0);
+#pragma unroll
+        for (uint32_t s = 0; s < Sg::STEPS; ++s) {
+            const uint32_t c = cx.g + 8 * s;
+            T e0 = u.a[s][0], e1 = u.a[s][1];
+            constexpr bool kRagged = Sg::COLS % 8 != 0;
+            bool keep = true;
+            if (kRagged && s == Sg::STEPS - 1) keep = cx.val[s];           // columns past the row
+            if (LASTROW && 8 * s + 7 >= n) keep = keep && c < n;           // R_{N-1} is never used (pcg.cuh:106)
+            if ((kRagged && s == Sg::STEPS - 1) || (LASTROW && 8 * s + 7 >= n)) {
+                e0 = keep ? e0 : T(0);
+                e1 = keep ? e1 : T(0);
+            }
+            const T xv = xk[c < Sg::COLS ? c : Sg::COLS - 1];
+            a0 = fma_t(e0, xv, a0);  // ... and their main products are never read
+            a1 = fma_t(e1, xv, a1);
+            if (8 * s + 7 >= n) {  // this step can touch R columns (compile-time)
+                const T tt = fma_t(e1, own.y, e0 * own.x);
+                t[s] = (8 * s >= n) ? tt : (c >= n ? tt : T(0));
+            } else {
+                t[s] = T(0);
+            }
+        }
+    }
+
     template <typename MainFn, typename TransFn>
     __device__ __forceinline__ void consume(uint32_t q, int slot, const T *x, uint32_t N, const SymCtx<T, NCT> &cx,
                                             bool refill, MainFn &&on_main, TransFn &&on_trans) {
         constexpr uint32_t n = Sg::N_;
         const uint32_t k = k_begin + q * k_step;
         const T *xk = x + k * n;
-        using P2 = typename VecOf<T, 2>::type;
-        P2 own = *reinterpret_cast<const P2 *>(xk + (cx.act ? cx.rp * 2 : 0u));
-        const bool lastrow = k == N - 1;
-        T a0 = T(0), a1 = T(0);
-        T t[Sg::STEPS];
-#pragma unroll
-        for (uint32_t s = 0; s < Sg::STEPS; ++s) {
-            const uint32_t c = cx.g + 8 * s;
-            const bool keep = cx.val[s] && !(lastrow && c >= n);  // R_{N-1} is never used (pcg.cuh:106)
-            const T e0 = keep ? ring[slot].a[s][0] : T(0), e1 = keep ? ring[slot].a[s][1] : T(0);
-            const T xv = xk[c < Sg::COLS ? c : Sg::COLS - 1];
-            a0 = fma_t(e0, xv, a0);
-            a1 = fma_t(e1, xv, a1);
-            t[s] = c >= n ? fma_t(e1, own.y, e0 * own.x) : T(0);
-        }
+        const bool lastrow = k == N - 1;  // wave-uniform
+        T a0, a1, t[Sg::STEPS];
+        if (lastrow) row_products<true>(ring[slot], xk, cx, a0, a1, t);
+        else row_products<false>(ring[slot], xk, cx, a0, a1, t);
         if (refill) issue(q + DEPTH, slot, cx);
 #pragma unroll
         for (uint32_t s = 0; s < Sg::STEPS; ++s) {
-            if (8 * s + 7 >= n) t[s] = sum_group8(t[s]);  // steps that can touch R columns (compile-time)
+            if (8 * s + 7 >= n) t[s] = sum_group8(t[s]);
         }
         a0 = sum_over_groups(a0);
         a1 = sum_over_groups(a1);

@@ -155,8 +155,9 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
                 ss.run(X + n, N, scx,
                        [&](uint32_t k, T a0, T a1) __attribute__((always_inline)) {
                            if (scx.g == 0 && scx.act) {
-                               yc[k * n + scx.rp * 2] = a0;
-                               yc[k * n + scx.rp * 2 + 1] = a1;
+                               using P2 = typename VecOf<T, 2>::type;
+                               P2 v2; v2.x = a0; v2.y = a1;
+                               *reinterpret_cast<P2 *>(yc + k * n + scx.rp * 2) = v2;  // n even: 2-element aligned
                            }
                        },
                        [&](uint32_t k, uint32_t c, T t) __attribute__((always_inline)) {

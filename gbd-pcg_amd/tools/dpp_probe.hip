@@ -1,3 +1,6 @@
+// dpp_probe.hip -- unit check of the cross-lane reductions used by bt_sym.hpp (DPP quad_perm / row_half_mirror /
+// row_ror) and of v_permlane16/32_swap, whose second result came back wrong on this toolchain (why bt_sym.hpp
+// uses xor shuffles for the cross-row part).  Prints the lane values; expected patterns are in the labels.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int CTRL> __device__ __forceinline__ float dpp_add_f(float v)

@@ -1,3 +1,5 @@
+"""Fits split-path solve time against the iteration count (per-iteration cost = 2 launches) for configs 4 and 2.
+Run on the GPU box from the repo root: python gbd-pcg_amd/tools/split_iter_fit.py"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
