@@ -241,7 +241,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "PCG iterations/sec (problem-iterations, block-tridiag stateSize x knotPoints = 14 x 128)",
+            "metric": "PCG iterations/sec and GB/s on block-tridiag SpMV, stateSize\u00d7knotPoints",
             "value": total_units / elapsed,
             "unit": "iter/s",
             "n_gpus": world,
@@ -260,6 +260,8 @@ def main():
                        "path": "fused (one workgroup per problem); default symmetric mode 2: device check, then [D|R] streaming",
                        "graph_ms_per_step": step_ms, "sharding": f"batch x{world}, no data-path collective"},
             "solves_per_sec": world * B * args.steps / elapsed,
+            "spmv_GBps": sp_gbps,
+            "value_definition": "problem-iterations per second (25 PCG iterations x 1024 problems per GPU per step), default path",
             "roofline": {"bound": "hbm", "kernel": "pcg_fused_kernel<float,14,2,8,true> (symmetric streaming)",
                          "achieved": pcg_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": pcg_gbps / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic("pcg_fused_kernel<float,14,2,8,true>"),

@@ -25,6 +25,7 @@ CONFIGS = [
     ("C4", 36, 256, 1, torch.float64),
     ("C2x64", 14, 64, 64, torch.float32),
     ("C4x16", 36, 256, 16, torch.float64),
+    ("C5on1", 14, 128, 8192, torch.float32),   # config 5's whole batch on one GPU
 ]
 
 
@@ -53,7 +54,9 @@ def main():
             continue
         es = 4 if dt == torch.float32 else 8
         g = synth.gen_torch(n, N, B, "cuda", dt, seed=1234)
-        S, P, gamma = g["S"], g["Pinv"], g["gamma"]
+        S, gamma = g["S"], g["gamma"]
+        P = solver.form_pinv(n, N, B, S, binding.PINV_STAIR)   # exactly symmetric storage (default path streams [D|R])
+        del g
         lam = torch.zeros_like(gamma)
         r, p = torch.empty_like(gamma), torch.empty_like(gamma)
         it = torch.zeros(B, dtype=torch.int32, device="cuda")
