@@ -9,10 +9,14 @@
 //   STAIR        : D slot = D_k^-1, L slot = -D_k^-1 L_k D_{k-1}^-1, R slot = -D_k^-1 R_k D_{k+1}^-1
 // (the symmetric-stair preconditioner of the MPCGPU paper the README cites, README.md:66-77).
 //
-// One workgroup per (problem, knot).  Pass 1 inverts D_k by Gauss-Jordan on an LDS-resident
+// One thread GROUP per (problem, knot): a whole 256-thread workgroup for large blocks, ONE WAVEFRONT
+// (four knots per workgroup) when n <= 24 -- these blocks are so small (n = 14: 196 elements) that a
+// knot is pure latency, and a wave needs no workgroup barrier: LDS operations of one wave execute in
+// program order, so a compiler-level fence between "everyone has read the old tableau" and "write the
+// new one" is all the synchronisation there is.  Pass 1 inverts D_k by Gauss-Jordan on an LDS-resident
 // [D | I] tableau (no pivoting: D_k is a definite diagonal block of a Schur complement); pass 2
-// (STAIR only) does the two triple products with all three operands in LDS.  This is O(n^3)
-// per knot on n^2 data and runs once per control step; it is not the bandwidth-bound hot loop.
+// (STAIR only) does the two triple products with all three operands in LDS.  O(n^3) per knot on n^2
+// data, once per control step; not the bandwidth-bound hot loop, but on the MPC critical path.
 #include "bt_device.hpp"
 #include "internal.hpp"
 
@@ -20,45 +24,60 @@ namespace gbdpcg {
 
 constexpr int kPinvThreads = 256;
 
-template <typename T>
-__global__ __launch_bounds__(kPinvThreads) void pinv_diag_kernel(uint32_t n, uint32_t N, const T *__restrict__ S,
-                                                                T *__restrict__ Pinv, int kind)
+// Synchronise the GT threads that share one knot.
+template <int GT> __device__ __forceinline__ void group_sync()
+{
+    if constexpr (GT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <typename T, int GT, int EPT_MAX>
+__global__ __launch_bounds__(kPinvThreads) void pinv_diag_kernel(uint32_t n, uint32_t N, uint64_t knots,
+                                                                const T *__restrict__ S, T *__restrict__ Pinv, int kind)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *tab = reinterpret_cast<T *>(smem_raw);  // [n][2n] row-major tableau
-    T *colj = tab + 2 * n * n;                 // [n] column j before elimination
-    const uint32_t tid = threadIdx.x;
-    const size_t blk = (size_t)blockIdx.x * 3 * n * n;  // (problem, knot) flattened: same stride
+    constexpr uint32_t GROUPS = kPinvThreads / GT;
+    const uint32_t grp = threadIdx.x / GT, tid = threadIdx.x % GT;
+    const uint64_t knot = (uint64_t)blockIdx.x * GROUPS + grp;  // (problem, knot) flattened: same stride
+    const uint32_t w = 2 * n;
+    T *tab = reinterpret_cast<T *>(smem_raw) + (size_t)grp * align16<T>(2 * n * n);  // [n][2n] row-major tableau
+    if (GT == 64 && knot >= knots) return;  // whole wave idle (only the wave-per-knot form has spare groups)
+    const size_t blk = (size_t)knot * 3 * n * n;
     const T *D = S + blk + (size_t)n * n;
     T *out = Pinv + blk;
-    const uint32_t w = 2 * n;
 
-    for (uint32_t i = tid; i < n * n; i += kPinvThreads) {
+    for (uint32_t i = tid; i < n * n; i += GT) {
         const uint32_t c = i / n, r = i - c * n;  // column-major source
         tab[r * w + c] = (kind == 0) ? (r == c ? T(1) : T(0)) : D[i];
         tab[r * w + n + c] = (r == c) ? T(1) : T(0);
     }
-    __syncthreads();
+    group_sync<GT>();
     if (kind != 0) {
         for (uint32_t j = 0; j < n; ++j) {
+            // every thread first READS what it needs of the old tableau (pivot, its column-j entries, the
+            // pivot row), then all WRITE: the two halves are separated by group_sync
             const T piv = T(1) / tab[j * w + j];
-            for (uint32_t r = tid; r < n; r += kPinvThreads) colj[r] = tab[r * w + j];
-            __syncthreads();
-            for (uint32_t i = tid; i < n * w; i += kPinvThreads) {
+            T upd[EPT_MAX];
+            uint32_t cnt = 0;
+            for (uint32_t i = tid; i < n * w && cnt < EPT_MAX; i += GT, ++cnt) {
                 const uint32_t r = i / w, c = i - r * w;
                 const T pr = tab[j * w + c] * piv;  // scaled pivot-row entry
-                if (r == j) continue;
-                tab[r * w + c] = fma_t(-colj[r], pr, tab[r * w + c]);
+                upd[cnt] = (r == j) ? pr : fma_t(-tab[r * w + j], pr, tab[r * w + c]);
             }
-            __syncthreads();
-            for (uint32_t c = tid; c < w; c += kPinvThreads) tab[j * w + c] *= piv;
-            __syncthreads();
+            group_sync<GT>();
+            cnt = 0;
+            for (uint32_t i = tid; i < n * w && cnt < EPT_MAX; i += GT, ++cnt) tab[i] = upd[cnt];
+            group_sync<GT>();
         }
     }
     // D_k^-1 of a symmetric D_k is symmetric in exact arithmetic but not bit for bit after the
     // elimination; the upper triangle is mirrored so that the stair blocks built from it come out
     // exactly symmetric (L_{k+1} == R_k^T) whenever S is -- what gbdpcg_set_symmetric relies on.
-    for (uint32_t i = tid; i < n * n; i += kPinvThreads) {
+    for (uint32_t i = tid; i < n * n; i += GT) {
         const uint32_t c = i / n, r = i - c * n;
         out[(size_t)n * n + i] = r <= c ? tab[r * w + n + c] : tab[c * w + n + r];
         out[i] = T(0);
@@ -67,19 +86,22 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_kernel(uint32_t n, uin
 }
 
 // Off-diagonal slots of the stair preconditioner; reads the D slots pass 1 wrote.
-template <typename T>
-__global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, uint32_t N, const T *__restrict__ S,
-                                                                 T *Pinv)
+template <typename T, int GT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, uint32_t N, uint64_t knots,
+                                                                 const T *__restrict__ S, T *Pinv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *A = reinterpret_cast<T *>(smem_raw);  // D_k^-1        (column-major)
-    T *B = A + n * n;                        // O_k           (L_k or R_k)
-    T *C = B + n * n;                        // D_{k+-1}^-1
-    T *W = C + n * n;                        // A*B
-    const uint32_t tid = threadIdx.x;
-    const uint32_t k = blockIdx.x % N;
-    const size_t blk = (size_t)blockIdx.x * 3 * n * n;
+    constexpr uint32_t GROUPS = kPinvThreads / GT;
+    const uint32_t grp = threadIdx.x / GT, tid = threadIdx.x % GT;
+    const uint64_t knot = (uint64_t)blockIdx.x * GROUPS + grp;
     const uint32_t nn = n * n;
+    T *A = reinterpret_cast<T *>(smem_raw) + (size_t)grp * align16<T>(4 * nn);  // first factor  (column-major)
+    T *B = A + nn;                                                              // middle factor
+    T *C = B + nn;                                                              // last factor
+    T *W = C + nn;                                                              // A*B
+    if (GT == 64 && knot >= knots) return;
+    const uint32_t k = (uint32_t)(knot % N);
+    const size_t blk = (size_t)knot * 3 * nn;
 
     // Right slot:  R'_k     = -(D_k^-1 R_k) D_{k+1}^-1.
     // Left slot :  L'_k     = -D_k^-1 L_k D_{k-1}^-1, evaluated as the TRANSPOSE of
@@ -87,9 +109,9 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, ui
     //              knot k-1 runs on (D_{k-1}^-1, R_{k-1}, D_k^-1).  With symmetric D^-1 blocks the two are
     //              equal as matrices for any S, and bit for bit each other's transpose when L_k == R_{k-1}^T.
     for (int side = 0; side < 2; ++side) {  // 0: left slot (needs k-1), 1: right slot (needs k+1)
-        if ((side == 0 && k == 0) || (side == 1 && k == N - 1)) continue;
+        if ((side == 0 && k == 0) || (side == 1 && k == N - 1)) continue;  // uniform over the group
         const size_t nb = side == 0 ? blk - (size_t)3 * nn : blk + (size_t)3 * nn;
-        for (uint32_t i = tid; i < nn; i += kPinvThreads) {
+        for (uint32_t i = tid; i < nn; i += GT) {
             const uint32_t c = i / n, r = i - c * n;
             if (side == 1) {
                 A[i] = Pinv[blk + nn + i];            // D_k^-1
@@ -101,36 +123,178 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, ui
                 C[i] = Pinv[blk + nn + i];            // D_k^-1
             }
         }
-        __syncthreads();
-        for (uint32_t i = tid; i < nn; i += kPinvThreads) {
+        group_sync<GT>();
+        for (uint32_t i = tid; i < nn; i += GT) {
             const uint32_t c = i / n, r = i - c * n;
             T acc = T(0);
             for (uint32_t q = 0; q < n; ++q) acc = fma_t(A[q * n + r], B[c * n + q], acc);
             W[i] = acc;
         }
-        __syncthreads();
-        for (uint32_t i = tid; i < nn; i += kPinvThreads) {
+        group_sync<GT>();
+        for (uint32_t i = tid; i < nn; i += GT) {
             const uint32_t c = i / n, r = i - c * n;
             T acc = T(0);
             for (uint32_t q = 0; q < n; ++q) acc = fma_t(W[q * n + r], C[c * n + q], acc);
             if (side == 1) Pinv[blk + 2 * (size_t)nn + i] = -acc;                  // R'_k(r,c)
             else Pinv[blk + (size_t)r * n + c] = -acc;                             // L'_k(c,r) = X(r,c)
         }
-        __syncthreads();
+        group_sync<GT>();
     }
 }
 
-template <typename T>
-hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
-                            int kind, hipStream_t s)
+// ---- compile-time block size, n <= 32: the [D | I] tableau lives in REGISTERS, one column per lane ----
+// Lane c < 2n owns tableau column c (n values).  Pivot step j needs column j (held by lane j) in every
+// lane: n v_readlane broadcasts into scalars, then n FMAs per lane -- no LDS, no barrier, the pivot loop
+// fully unrolled so every register index is static.  Same arithmetic, element for element, as the LDS
+// kernel above.  One wavefront per knot, four knots per workgroup.
+__device__ __forceinline__ float lane_bcast(float v, int lane)
 {
-    const size_t lds1 = ((size_t)2 * n * n + n) * sizeof(T);
-    const size_t lds2 = (size_t)4 * n * n * sizeof(T);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_diag_reg_kernel(uint32_t N, uint64_t knots, const T *__restrict__ S,
+                                                                    T *__restrict__ Pinv, int kind)
+{
+    constexpr uint32_t n = NCT, nn = n * n;
+    __shared__ T stage_all[4][nn];  // D_k^-1 of each wave's knot, for the mirrored write-out
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t knot = (uint64_t)blockIdx.x * 4 + wave;
+    if (knot >= knots) return;
+    T *stage = stage_all[wave];
+    const size_t blk = (size_t)knot * 3 * nn;
+    const T *D = S + blk + nn;
+    T *out = Pinv + blk;
+
+    T col[n];
+#pragma unroll
+    for (uint32_t r = 0; r < n; ++r) {
+        if (lane < n) col[r] = (kind == 0) ? (r == lane ? T(1) : T(0)) : D[lane * n + r];
+        else col[r] = (lane - n == r) ? T(1) : T(0);
+    }
+    if (kind != 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) {
+            T cj[n];
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) cj[r] = lane_bcast(col[r], (int)j);
+            const T piv = T(1) / cj[j];
+            const T pr = col[j] * piv;  // scaled pivot-row entry of this lane's column
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) col[r] = (r == j) ? pr : fma_t(-cj[r], pr, col[r]);
+        }
+    }
+    // lanes n .. 2n-1 hold the columns of D_k^-1; mirror the upper triangle (see the LDS kernel) on the way out
+    if (lane >= n && lane < 2 * n) {
+#pragma unroll
+        for (uint32_t r = 0; r < n; ++r) stage[(lane - n) * n + r] = col[r];
+    }
+    group_sync<64>();
+    for (uint32_t i = lane; i < nn; i += 64) {
+        const uint32_t c = i / n, r = i - c * n;
+        out[nn + i] = r <= c ? stage[c * n + r] : stage[r * n + c];
+        // the stair pass overwrites every off-diagonal slot except the two never-read corner blocks
+        const uint32_t kk = (uint32_t)(knot % N);
+        if (kind != 2 || kk == 0) out[i] = T(0);
+        if (kind != 2 || kk == N - 1) out[2 * nn + i] = T(0);
+    }
+}
+
+// Stair off-diagonal slots for compile-time n: one wavefront per knot, every inner product reads BOTH
+// operands as contiguous pairs from LDS.  D^-1 blocks are exactly symmetric (mirrored by pass 1), so row r
+// of the first factor is its column r; the intermediate W = A*B is stored transposed for the same reason.
+// Operation order is the LDS kernel's ((A*B)*C, q ascending), so both produce the same bits.
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N, uint64_t knots, const T *__restrict__ S,
+                                                                     T *Pinv)
+{
+    constexpr uint32_t n = NCT, nn = n * n;
+    using P2 = typename VecOf<T, 2>::type;
+    __shared__ __attribute__((aligned(16))) T lds[4][4 * nn];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t knot = (uint64_t)blockIdx.x * 4 + wave;
+    if (knot >= knots) return;
+    T *A = lds[wave], *B = A + nn, *C = B + nn, *Wt = C + nn;
+    const uint32_t k = (uint32_t)(knot % N);
+    const size_t blk = (size_t)knot * 3 * nn;
+
+    for (int side = 0; side < 2; ++side) {  // 0: left slot (needs k-1), 1: right slot (needs k+1)
+        if ((side == 0 && k == 0) || (side == 1 && k == N - 1)) continue;  // wave-uniform
+        const size_t nb = side == 0 ? blk - (size_t)3 * nn : blk + (size_t)3 * nn;
+        for (uint32_t i = lane; i < nn; i += 64) {
+            const uint32_t c = i / n, r = i - c * n;
+            if (side == 1) {
+                A[i] = Pinv[blk + nn + i];            // D_k^-1
+                B[i] = S[blk + 2 * (size_t)nn + i];   // R_k
+                C[i] = Pinv[nb + nn + i];             // D_{k+1}^-1
+            } else {
+                A[i] = Pinv[nb + nn + i];             // D_{k-1}^-1
+                B[i] = S[blk + (size_t)r * n + c];    // L_k^T : element (r,c) = L_k(c,r)
+                C[i] = Pinv[blk + nn + i];            // D_k^-1
+            }
+        }
+        group_sync<64>();
+        for (uint32_t i = lane; i < nn; i += 64) {
+            const uint32_t c = i / n, r = i - c * n;
+            // W(r,c) = sum_q A(r,q) B(q,c);  A symmetric: A(r,q) = A(q,r) = A[r*n + q]
+            T acc = T(0);
+            if constexpr (n % 2 == 0) {
+                const P2 *ar = reinterpret_cast<const P2 *>(A + r * n), *bc = reinterpret_cast<const P2 *>(B + c * n);
+#pragma unroll
+                for (uint32_t q = 0; q < n / 2; ++q) {
+                    const P2 a2 = ar[q], b2 = bc[q];
+                    acc = fma_t(a2.x, b2.x, acc);
+                    acc = fma_t(a2.y, b2.y, acc);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < n; ++q) acc = fma_t(A[r * n + q], B[c * n + q], acc);
+            }
+            Wt[r * n + c] = acc;  // transposed: row r of W contiguous
+        }
+        group_sync<64>();
+        for (uint32_t i = lane; i < nn; i += 64) {
+            const uint32_t c = i / n, r = i - c * n;
+            T acc = T(0);
+            if constexpr (n % 2 == 0) {
+                const P2 *wr = reinterpret_cast<const P2 *>(Wt + r * n), *cc = reinterpret_cast<const P2 *>(C + c * n);
+#pragma unroll
+                for (uint32_t q = 0; q < n / 2; ++q) {
+                    const P2 w2 = wr[q], c2 = cc[q];
+                    acc = fma_t(w2.x, c2.x, acc);
+                    acc = fma_t(w2.y, c2.y, acc);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < n; ++q) acc = fma_t(Wt[r * n + q], C[c * n + q], acc);
+            }
+            if (side == 1) Pinv[blk + 2 * (size_t)nn + i] = -acc;                  // R'_k(r,c)
+            else Pinv[blk + (size_t)r * n + c] = -acc;                             // L'_k(c,r) = X(r,c)
+        }
+        group_sync<64>();
+    }
+}
+
+template <typename T, int GT, int EPT_MAX>
+static hipError_t launch_form_pinv_g(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
+                                     int kind, hipStream_t s)
+{
+    constexpr uint32_t GROUPS = kPinvThreads / GT;
+    const size_t lds1 = (size_t)GROUPS * align16<T>(2 * n * n) * sizeof(T);
+    const size_t lds2 = (size_t)GROUPS * align16<T>(4 * n * n) * sizeof(T);
     if (lds1 > dev.lds_per_wg_max || lds2 > dev.lds_per_wg_max) return hipErrorInvalidValue;
-    const uint64_t blocks = (uint64_t)N * batch;
+    const uint64_t knots = (uint64_t)N * batch;
+    const uint64_t blocks = (knots + GROUPS - 1) / GROUPS;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    auto k1 = pinv_diag_kernel<T>;
-    auto k2 = pinv_stair_kernel<T>;
+    auto k1 = pinv_diag_kernel<T, GT, EPT_MAX>;
+    auto k2 = pinv_stair_kernel<T, GT>;
     if (lds1 > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return e;
@@ -139,9 +303,54 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
         hipError_t e = hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k1, dim3((uint32_t)blocks), dim3(kPinvThreads), lds1, s, n, N, S, Pinv, kind);
-    if (kind == 2) hipLaunchKernelGGL(k2, dim3((uint32_t)blocks), dim3(kPinvThreads), lds2, s, n, N, S, Pinv);
+    hipLaunchKernelGGL(k1, dim3((uint32_t)blocks), dim3(kPinvThreads), lds1, s, n, N, knots, S, Pinv, kind);
+    if (kind == 2) hipLaunchKernelGGL(k2, dim3((uint32_t)blocks), dim3(kPinvThreads), lds2, s, n, N, knots, S, Pinv);
     return hipGetLastError();
+}
+
+template <typename T, int GT>
+static hipError_t launch_stair_only(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
+                                    hipStream_t s)
+{
+    constexpr uint32_t GROUPS = kPinvThreads / GT;
+    const size_t lds2 = (size_t)GROUPS * align16<T>(4 * n * n) * sizeof(T);
+    if (lds2 > dev.lds_per_wg_max) return hipErrorInvalidValue;
+    const uint64_t knots = (uint64_t)N * batch, blocks = (knots + GROUPS - 1) / GROUPS;
+    auto k2 = pinv_stair_kernel<T, GT>;
+    if (lds2 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k2, dim3((uint32_t)blocks), dim3(kPinvThreads), lds2, s, n, N, knots, S, Pinv);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
+                            int kind, hipStream_t s)
+{
+    // register-resident tableau for the compile-time block sizes with 2n <= 64 lanes
+#define GBDPCG_CASE(NN)                                                                                              \
+    if constexpr (2 * NN <= 64) {                                                                                    \
+        if (n == NN) {                                                                                               \
+            const uint64_t knots = (uint64_t)N * batch, blocks = (knots + 3) / 4;                                    \
+            if (blocks > 0x7fffffffull) return hipErrorInvalidValue;                                                 \
+            hipLaunchKernelGGL((pinv_diag_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, S, \
+                               Pinv, kind);                                                                          \
+            if (kind != 2) return hipGetLastError();                                                                 \
+            hipLaunchKernelGGL((pinv_stair_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, S, \
+                               Pinv);                                                                                \
+            return hipGetLastError();                                                                                \
+        }                                                                                                            \
+    }
+    GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
+    // wave-per-knot needs the whole [D|I] tableau to fit 16 elements per lane: 2 n^2 <= 1024
+    // (EPT_MAX tableau elements per thread are held in registers across the read / write halves of a pivot step)
+    if (2 * n * n <= 16 * 64) return launch_form_pinv_g<T, 64, 16>(dev, n, N, batch, S, Pinv, kind, s);
+    if (2 * n * n <= 16 * 256) return launch_form_pinv_g<T, 256, 16>(dev, n, N, batch, S, Pinv, kind, s);
+    if (2 * n * n <= 64 * 256) return launch_form_pinv_g<T, 256, 64>(dev, n, N, batch, S, Pinv, kind, s);
+    return hipErrorInvalidValue;
 }
 
 template hipError_t launch_form_pinv<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const float *,
