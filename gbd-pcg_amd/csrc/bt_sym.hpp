@@ -83,7 +83,7 @@ template <typename T, int NCT> struct SymCtx {
 
 // Same prime / run protocol as RowStream (bt_device.hpp): a ring of DEPTH rows in registers,
 // branch-free priming, counted waits in the steady state.
-template <typename T, int NCT> struct SymStream {
+template <typename T, int NCT, bool NT = false> struct SymStream {
     using Sg = SymGeom<T, NCT>;
     static constexpr int DEPTH = Sg::DEPTH;
     struct Unit { T a[Sg::STEPS][2]; };
@@ -95,7 +95,7 @@ template <typename T, int NCT> struct SymStream {
         const uint32_t k = q < total ? k_begin + q * k_step : 0u;
         const T *base = M + (size_t)k * 3 * Sg::N_ * Sg::N_ + Sg::N_ * Sg::N_;
 #pragma unroll
-        for (uint32_t s = 0; s < Sg::STEPS; ++s) VecIO<T, 2>::load(base + cx.off[s], ring[slot].a[s]);
+        for (uint32_t s = 0; s < Sg::STEPS; ++s) VecIO<T, 2>::template load<NT>(base + cx.off[s], ring[slot].a[s]);
     }
 
     __device__ __forceinline__ void prime(const T *__restrict__ M_, uint32_t k_begin_, uint32_t k_end_, uint32_t k_step_,

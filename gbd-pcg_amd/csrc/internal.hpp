@@ -73,6 +73,10 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
 template <typename T> bool resident_shape(uint32_t n, uint32_t N);  // shape handled by the resident kernel
 template <typename T>
 bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
+// Symmetric matrices resident on one CU (pcg_resident_sym.hip): n = 14, fp32, N <= 128, a.symmetric set.
+template <typename T> bool resident_sym_shape(uint32_t n, uint32_t N);
+template <typename T>
+bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
 
 // ---- pcg_split.hip : many workgroups per problem, two launches per iteration
 template <typename T> size_t split_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);

@@ -21,6 +21,12 @@
 
 namespace gbdpcg {
 
+// The matrices are re-read every iteration and largely served by the Infinity Cache: default policy.
+#ifndef GBDPCG_PCG_NT
+#define GBDPCG_PCG_NT 0
+#endif
+constexpr bool kPcgNT = GBDPCG_PCG_NT != 0;
+
 // LDS carve (elements of T), every array 16-byte aligned:
 //   xa  (N+2)n   padded SpMV input: lambda in the prologue, then p      (pads stay zero)
 //   xb  (N+2)n   padded SpMV input: r
@@ -45,7 +51,7 @@ template <typename T> struct FusedCarve {
 // y = M * X (X padded in LDS) for the block-rows of this wave, out of an already primed stream;
 // returns this LANE's partial of dot(y, D) where D is a padded LDS vector (D + n = first element).
 template <typename T, int NCT, int V>
-__device__ __forceinline__ T wg_spmv_dot(RowStream<T, NCT, V> &rs, const T *X, T *Y, const T *D,
+__device__ __forceinline__ T wg_spmv_dot(RowStream<T, NCT, V, kPcgNT> &rs, const T *X, T *Y, const T *D,
                                          const LaneMap<NCT, V> &m, const StreamCtx<T, NCT, V> &cx, uint32_t n,
                                          uint32_t N, uint32_t lane)
 {
@@ -97,9 +103,9 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     T *zc = smem + cv.zc;
     const LaneMap<NCT, V> m(n, lane);
     const StreamCtx<T, NCT, V> cx(m, lane);
-    RowStream<T, NCT, V> rs;
+    RowStream<T, NCT, V, kPcgNT> rs;
     const SymCtx<T, NCT> scx(lane);
-    SymStream<T, NCT> ss;
+    SymStream<T, NCT, kPcgNT> ss;
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
@@ -229,8 +235,9 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
 
 template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch)
 {
-    if (batch < (uint32_t)dev.num_cus) return false;  // small batches: not worth the symmetry check
     if (resident_shape<T>(n, N)) return false;         // register-resident kernel reads each matrix once anyway
+    if (resident_sym_shape<T>(n, N)) return true;      // symmetric halves fit one CU: pcg_resident_sym.hip
+    if (batch < (uint32_t)dev.num_cus) return false;  // small batches: not worth the symmetry check
     bool ok = false;
 #define GBDPCG_CASE(NN) \
     if (n == NN) ok = SymGeom<T, NN>::OK && best_v<T, NN>() >= 2;
@@ -327,6 +334,7 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
 {
     hipError_t rerr = hipSuccess;
     if (launch_pcg_resident<T>(dev, a, s, &rerr)) return rerr;  // small problems: pcg_resident.hip
+    if (a.symmetric && launch_pcg_resident_sym<T>(dev, a, s, &rerr)) return rerr;  // pcg_resident_sym.hip
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
     if (V == 0) return hipErrorInvalidValue;

@@ -1,0 +1,369 @@
+// pcg_resident_sym.hip -- PCG with both SYMMETRIC matrices resident on one CU (registers + LDS).
+//
+// Replaces pcg<T,n,N> (/root/reference/include/pcg.cuh:54-218) for the BASELINE batch shape
+// (n = 14, fp32, N <= 128) when S and Pinv are symmetric in storage (L_{k+1} == R_k^T, tested on the
+// device or asserted by the caller, gbdpcg_set_symmetric).  The symmetric halves [D_k | R_k] of BOTH
+// matrices are 2 * 128 * 2n^2 * 4 B = 401 KB: three quarters live in the registers of one 8-wave
+// workgroup (3 x 56 VGPRs per lane), the last quarter in LDS (114.7 KB), so the matrices are read
+// from HBM ONCE PER SOLVE and an iteration moves no bytes beyond the CU -- the reference's idea of
+// keeping the block-rows next to the ALUs for the whole solve (pcg.cuh:104-110), with the whole
+// problem inside one workgroup so that no grid barrier exists.
+//
+// Lane map: aligned groups of 8 lanes; lane rp = lane & 7 < 7 owns rows 2rp, 2rp+1 of TWO consecutive
+// block-rows k0 = 2j, k1 = 2j+1 (j = 8*wave + group): all 2n columns of [D_k | R_k], 56 registers per
+// block-row per matrix.  Per block-row and product
+//     y_k     +=  [D_k | R_k] [x_k ; x_{k+1}]    2n FMAs per row, columns ascending, no cross-lane fold
+//     y_{k+1} +=  R_k^T x_k                      n partial values per lane, reduce-scattered over the
+//                                                8 lanes of the group with DPP (half-mirror, quad
+//                                                perms): lane rp ends up with entries 2rp, 2rp+1
+// The transposed product of k0 lands in the same lane's k1 rows (registers); the one of k1 belongs to
+// the next group and goes through LDS.  Its share of the inner product is accounted on the producer
+// side (u . x_{k1+1}), so the workgroup reduction needs no extra barrier: 4 barriers per iteration.
+#include <cstdlib>
+
+#include "bt_device.hpp"
+#include "bt_sym.hpp"
+#include "internal.hpp"
+
+namespace gbdpcg {
+
+template <int NCT> struct SymResGeom {
+    static constexpr uint32_t N_ = NCT;
+    static constexpr uint32_t QUADS = N_;            // 16-byte pieces per lane per block-row: 2 columns x 2 rows
+    static constexpr uint32_t WAVES = 8, GROUPS = 8, SLOTS = 2;
+    static constexpr uint32_t THREADS = WAVES * 64;
+    static constexpr uint32_t MAX_KNOTS = WAVES * GROUPS * SLOTS;
+    static constexpr uint32_t TILE_LDS_FLOATS = QUADS * THREADS * 4;
+};
+
+// One block-row of one matrix as this lane sees it: q[i] = (M[2rp, 2i], M[2rp+1, 2i], M[2rp, 2i+1], M[2rp+1, 2i+1])
+// over the 2n columns of [D | R].
+template <int NCT> struct SymResTile {
+    float4 q[SymResGeom<NCT>::QUADS];
+};
+
+template <int NCT>
+__device__ __forceinline__ void symres_load(const float *__restrict__ M, uint32_t N, uint32_t k, uint32_t rp, bool live,
+                                            SymResTile<NCT> &t)
+{
+    constexpr uint32_t n = NCT;
+    const float *src = M + (size_t)(live ? k : 0u) * 3 * n * n + n * n + (live ? rp * 2 : 0u);
+    const bool keep_r = live && k != N - 1;  // R_{N-1} is never used (pcg.cuh:106)
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) {
+        float a[2], b[2];
+        VecIO<float, 2>::load<true>(src + (2 * i) * n, a);
+        VecIO<float, 2>::load<true>(src + (2 * i + 1) * n, b);
+        const bool keep = 2 * i < n ? live : keep_r;
+        t.q[i] = make_float4(keep ? a[0] : 0.f, keep ? a[1] : 0.f, keep ? b[0] : 0.f, keep ? b[1] : 0.f);
+    }
+    // Pin the masked values here: hipcc otherwise sinks the selects to the first use and keeps the raw
+    // and the masked copy of every tile alive across the prologue (spills).
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) asm volatile("" : "+v"(t.q[i].x), "+v"(t.q[i].y), "+v"(t.q[i].z), "+v"(t.q[i].w));
+}
+
+// acc = [D|R] rows of this lane times [x_k; x_{k+1}] (xk2 = 8-byte pairs starting at x_k);
+// tt[c] = R[2rp, c] own0 + R[2rp+1, c] own1, the lane's share of (R^T x_k)[c].
+// The LDS operands are fetched AHEAD steps early and the steps are pinned in source order: left to
+// itself hipcc hoists all 14 + 14 LDS reads to the top (84 VGPRs), which with three resident tiles
+// (168 VGPRs) spills.
+template <int NCT, bool FROM_LDS>
+__device__ __forceinline__ void symres_mv(const SymResTile<NCT> &t, const float4 *lt, const float2 *xk2, float own0,
+                                          float own1, float (&acc)[2], float (&tt)[NCT])
+{
+    constexpr uint32_t n = NCT;
+    constexpr uint32_t AHEAD = 3;
+    float2 xq[AHEAD + 1];
+    float4 vq[AHEAD + 1];
+#pragma unroll
+    for (uint32_t i = 0; i < AHEAD; ++i) {
+        xq[i] = xk2[i];
+        if (FROM_LDS) vq[i] = lt[i * SymResGeom<NCT>::THREADS];
+    }
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f av = {0.f, 0.f};  // (row 2rp, row 2rp+1): one v_pk_fma_f32 per column
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i + AHEAD < n) {
+            xq[(i + AHEAD) % (AHEAD + 1)] = xk2[i + AHEAD];
+            if (FROM_LDS) vq[(i + AHEAD) % (AHEAD + 1)] = lt[(i + AHEAD) * SymResGeom<NCT>::THREADS];
+        }
+        const float4 v = FROM_LDS ? vq[i % (AHEAD + 1)] : t.q[i];
+        const float2 xv = xq[i % (AHEAD + 1)];
+        av = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, av);
+        av = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, av);
+        if (2 * i >= n) {
+            tt[2 * i - n] = fma_t(v.y, own1, v.x * own0);
+            tt[2 * i - n + 1] = fma_t(v.w, own1, v.z * own0);
+        }
+        // anchor the step: without it the accumulator chain is sunk below the reduce-scatter and the
+        // operands of all 14 steps stay live
+        asm volatile("" : "+v"(av) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[0] = av.x;
+    acc[1] = av.y;
+}
+
+// Sum tt[c] over the 8 lanes of the aligned group and leave entries 2rp, 2rp+1 in lane rp:
+// recursive halving, partner 7-i (row_half_mirror), then i^2 and i^1 (quad perms).  The DPP adds are
+// written as asm blocks: hipcc otherwise pairs the adds into v_pk_add_f32 fed by v_mov_b32_dpp copies
+// (3x the instructions).  Each block starts with the two wait states a DPP read of a freshly written
+// VGPR needs; inside a block every instruction touches its own register.
+#define GBDPCG_DPP_ADD(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"
+__device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2])
+{
+#define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_half_mirror row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7) D(8) D(9) D(10) D(11) D(12) D(13)
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                   "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]));
+#undef D
+    const bool hi = (lane & 4u) != 0;
+    float u0 = hi ? t[8] : t[0], u1 = hi ? t[9] : t[1], u2 = hi ? t[10] : t[2], u3 = hi ? t[11] : t[3];
+    float u4 = hi ? t[12] : t[4], u5 = hi ? t[13] : t[5], u6 = hi ? 0.f : t[6], u7 = hi ? 0.f : t[7];
+#define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7)
+                 : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));
+#undef D
+    const bool b1 = (lane & 2u) != 0;
+    float w0 = b1 ? u4 : u0, w1 = b1 ? u5 : u1, w2 = b1 ? u6 : u2, w3 = b1 ? u7 : u3;
+#define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+#undef D
+    const bool b0 = (lane & 1u) != 0;
+    out[0] = b0 ? w2 : w0;
+    out[1] = b0 ? w3 : w1;
+}
+#undef GBDPCG_DPP_ADD
+
+template <int WAVES> __device__ __forceinline__ float symres_wg_sum(float part, float *red, uint32_t lane, uint32_t wave)
+{
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    float tot = red[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) tot += red[w];
+    return tot;
+}
+
+template <int NCT>
+__global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
+{
+    using G = SymResGeom<NCT>;
+    static_assert(G::THREADS == 512, "launch bounds above assume 8 waves");
+    static_assert(NCT == 14, "the reduce-scatter is written for 7 live lanes x 2 rows");
+    constexpr uint32_t n = NCT, WAVES = G::WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *smem = reinterpret_cast<float *>(smem_raw);
+
+    const uint32_t N = a.N, len = n * N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t padded = align16<float>((N + 2) * n);
+    float4 *lt = reinterpret_cast<float4 *>(smem) + tid;  // this lane's column of the LDS-resident tile (Pinv, k1)
+    float *xa = smem + G::TILE_LDS_FLOATS, *xb = xa + padded;  // padded mirrors of p (lambda in the prologue) and r
+    float *zs = xb + padded;                                   // R_{k-1}^T x_{k-1} for the even block-rows
+    float *red0 = zs + padded, *red1 = red0 + WAVES;
+    float *ls = red1 + WAVES;                                  // lambda
+
+    const uint32_t rp = lane & 7u;
+    const uint32_t k0 = 2 * (wave * G::GROUPS + (lane >> 3)), k1 = k0 + 1;
+    const bool live0 = rp < n / 2 && k0 < N, live1 = rp < n / 2 && k1 < N;
+    const uint32_t row0 = (live0 ? k0 * n + rp * 2 : 0u), row1 = (live1 ? k1 * n + rp * 2 : 0u);
+    // x operand windows inside a padded mirror (n zeros before x_0 and after x_{N-1}); dead lanes read row 0
+    const uint32_t xo0 = n + (live0 ? k0 : 0u) * n, xo1 = n + (live1 ? k1 : 0u) * n;
+    const uint32_t zo1 = n + (live1 ? k1 + 1 : 0u) * n + rp * 2;  // where this lane's k1 -> k1+1 products go
+    const uint32_t zo0 = n + (live0 ? k0 : 0u) * n + rp * 2;      // ... and where the ones for its k0 rows arrive
+    const size_t mstride = (size_t)3 * n * n * N;
+
+    for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
+        if (a.sel && a.sel[prob] != a.want) continue;  // this launch is not the one that owns the problem
+        const float *S = a.S + prob * mstride;
+        const float *P = a.Pinv + prob * mstride;
+        const size_t voff = (size_t)prob * len;
+
+        // Resident for the whole solve: three tiles in registers, the fourth in LDS.  Everything else
+        // (lambda, r, p) lives in LDS between the phases; only y crosses a barrier in registers.
+        SymResTile<NCT> s0, s1, p0;
+        {
+            SymResTile<NCT> p1;
+            symres_load<NCT>(P, N, k1, rp, live1, p1);
+#pragma unroll
+            for (uint32_t i = 0; i < n; ++i) lt[i * G::THREADS] = p1.q[i];
+        }
+        symres_load<NCT>(S, N, k0, rp, live0, s0);
+        symres_load<NCT>(S, N, k1, rp, live1, s1);
+        symres_load<NCT>(P, N, k0, rp, live0, p0);
+
+        for (uint32_t i = tid; i < len; i += G::THREADS) {
+            const float l = a.lambda[voff + i];
+            ls[i] = l;
+            xa[n + i] = l;
+        }
+        for (uint32_t i = tid; i < n; i += G::THREADS) {
+            xa[i] = 0.f; xa[n + len + i] = 0.f;
+            xb[i] = 0.f; xb[n + len + i] = 0.f;
+            zs[n + i] = 0.f;  // block-row 0 has nothing above it; never written afterwards
+        }
+        __syncthreads();
+
+        // One matrix-vector product over this lane's two block-rows.  XM: padded mirror of the operand.
+        // Leaves y[1] complete and y[0] without the rows' share of R_{k0-1}^T x_{k0-1}, which the previous
+        // group puts into zs (GBDPCG_SYMRES_FINISH_Y reads it after the next barrier); PART = the lane's
+        // share of x . (M x) INCLUDING what it sent to zs.
+#define GBDPCG_SYMRES_PRODUCT(T0, T1, T1_FROM_LDS, XM, PART)                                                  \
+        {                                                                                                     \
+            float tt[NCT], u0[2], u1[2];                                                                      \
+            float2 o0 = *reinterpret_cast<const float2 *>(XM + n + row0);                                     \
+            float2 o1 = *reinterpret_cast<const float2 *>(XM + n + row1);                                     \
+            o0.x = live0 ? o0.x : 0.f; o0.y = live0 ? o0.y : 0.f;                                             \
+            o1.x = live1 ? o1.x : 0.f; o1.y = live1 ? o1.y : 0.f;                                             \
+            symres_mv<NCT, false>(T0, nullptr, reinterpret_cast<const float2 *>(XM + xo0), o0.x, o0.y, y[0], tt); \
+            symres_reduce_scatter14(tt, lane, u0);                                                            \
+            symres_mv<NCT, T1_FROM_LDS>(T1, lt, reinterpret_cast<const float2 *>(XM + xo1), o1.x, o1.y, y[1], tt); \
+            symres_reduce_scatter14(tt, lane, u1);                                                            \
+            y[1][0] += u0[0];                                                                                 \
+            y[1][1] += u0[1];                                                                                 \
+            if (live1) *reinterpret_cast<float2 *>(zs + zo1) = make_float2(u1[0], u1[1]);                     \
+            const float2 xn = *reinterpret_cast<const float2 *>(XM + zo1);                                    \
+            PART = o0.x * y[0][0];                                                                            \
+            PART = fma_t(o0.y, y[0][1], PART);                                                                \
+            PART = fma_t(o1.x, y[1][0], PART);                                                                \
+            PART = fma_t(o1.y, y[1][1], PART);                                                                \
+            PART = fma_t(live1 ? u1[0] : 0.f, xn.x, PART);                                                    \
+            PART = fma_t(live1 ? u1[1] : 0.f, xn.y, PART);                                                    \
+        }
+#define GBDPCG_SYMRES_FINISH_Y()                                                                              \
+        {                                                                                                     \
+            const float2 z = *reinterpret_cast<const float2 *>(zs + zo0);                                     \
+            y[0][0] += live0 ? z.x : 0.f;                                                                     \
+            y[0][1] += live0 ? z.y : 0.f;                                                                     \
+        }
+        float2 *xa0 = reinterpret_cast<float2 *>(xa + n + row0), *xa1 = reinterpret_cast<float2 *>(xa + n + row1);
+        float2 *xb0 = reinterpret_cast<float2 *>(xb + n + row0), *xb1 = reinterpret_cast<float2 *>(xb + n + row1);
+        float2 *ls0 = reinterpret_cast<float2 *>(ls + row0), *ls1 = reinterpret_cast<float2 *>(ls + row1);
+
+        float y[2][2], part;
+        // r = gamma - S lambda                                            (pcg.cuh:118-126)
+        GBDPCG_SYMRES_PRODUCT(s0, s1, false, xa, part)
+        __syncthreads();
+        GBDPCG_SYMRES_FINISH_Y()
+        if (live0) *xb0 = make_float2(a.gamma[voff + row0] - y[0][0], a.gamma[voff + row0 + 1] - y[0][1]);
+        if (live1) *xb1 = make_float2(a.gamma[voff + row1] - y[1][0], a.gamma[voff + row1 + 1] - y[1][1]);
+        __syncthreads();
+
+        // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
+        GBDPCG_SYMRES_PRODUCT(p0, p0, true, xb, part)
+        float eta = symres_wg_sum<WAVES>(part, red1, lane, wave);
+        GBDPCG_SYMRES_FINISH_Y()
+        if (live0) *xa0 = make_float2(y[0][0], y[0][1]);
+        if (live1) *xa1 = make_float2(y[1][0], y[1][1]);
+        __syncthreads();
+
+        uint32_t iter = 0;
+        bool max_iter_exit = true;
+        for (; iter < a.max_iter; ++iter) {                               // pcg.cuh:154
+            // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
+            GBDPCG_SYMRES_PRODUCT(s0, s1, false, xa, part)
+            const float alpha = eta / symres_wg_sum<WAVES>(part, red0, lane, wave);
+            GBDPCG_SYMRES_FINISH_Y()
+            // lambda += alpha p ; r -= alpha upsilon                      (pcg.cuh:172-176)
+            if (live0) {
+                const float2 pp = *xa0, ll = *ls0, rr = *xb0;
+                *ls0 = make_float2(fma_t(alpha, pp.x, ll.x), fma_t(alpha, pp.y, ll.y));
+                *xb0 = make_float2(fma_t(-alpha, y[0][0], rr.x), fma_t(-alpha, y[0][1], rr.y));
+            }
+            if (live1) {
+                const float2 pp = *xa1, ll = *ls1, rr = *xb1;
+                *ls1 = make_float2(fma_t(alpha, pp.x, ll.x), fma_t(alpha, pp.y, ll.y));
+                *xb1 = make_float2(fma_t(-alpha, y[1][0], rr.x), fma_t(-alpha, y[1][1], rr.y));
+            }
+            __syncthreads();
+            // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
+            GBDPCG_SYMRES_PRODUCT(p0, p0, true, xb, part)
+            const float eta_new = symres_wg_sum<WAVES>(part, red1, lane, wave);
+            GBDPCG_SYMRES_FINISH_Y()
+            if (fabsf(eta_new) < a.tol) {                                 // pcg.cuh:195
+                ++iter;
+                max_iter_exit = false;
+                break;
+            }
+            const float beta = eta_new / eta;                             // pcg.cuh:199-206
+            eta = eta_new;
+            if (live0) {
+                const float2 pp = *xa0;
+                *xa0 = make_float2(fma_t(beta, pp.x, y[0][0]), fma_t(beta, pp.y, y[0][1]));
+            }
+            if (live1) {
+                const float2 pp = *xa1;
+                *xa1 = make_float2(fma_t(beta, pp.x, y[1][0]), fma_t(beta, pp.y, y[1][1]));
+            }
+            __syncthreads();
+        }
+#undef GBDPCG_SYMRES_PRODUCT
+#undef GBDPCG_SYMRES_FINISH_Y
+
+        // outputs                                                         (pcg.cuh:212,215)
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += G::THREADS) {
+            a.lambda[voff + i] = ls[i];
+            if (a.r) a.r[voff + i] = xb[n + i];
+            if (a.p) a.p[voff + i] = xa[n + i];
+        }
+        if (tid == 0) {
+            a.iters[prob] = iter;
+            if (a.max_iter_exit) a.max_iter_exit[prob] = max_iter_exit ? 1 : 0;
+        }
+        __syncthreads();  // LDS (tile, vectors) is reused by the next problem
+    }
+}
+
+// n = 14, fp32, N <= 128, a preconditioner given, matrices 8-byte aligned.  GBDPCG_NO_RESIDENT_SYM
+// disables the path (tuning runs).
+template <typename T> bool resident_sym_shape(uint32_t n, uint32_t N)
+{
+    static const bool off = getenv("GBDPCG_NO_RESIDENT_SYM") != nullptr;
+    if (off || sizeof(T) != 4 || n != 14) return false;
+    return N <= SymResGeom<14>::MAX_KNOTS;
+}
+
+static size_t resident_sym_lds(uint32_t n, uint32_t N)
+{
+    return ((size_t)SymResGeom<14>::TILE_LDS_FLOATS + 3 * (size_t)align16<float>((N + 2) * n) +
+            2 * SymResGeom<14>::WAVES + align16<float>(N * n)) * sizeof(float);
+}
+
+template <typename T>
+bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (!a.symmetric || !a.Pinv || !resident_sym_shape<T>(a.n, a.N)) return false;
+        if ((reinterpret_cast<uintptr_t>(a.S) % 8) || (reinterpret_cast<uintptr_t>(a.Pinv) % 8)) return false;
+        const size_t lds = resident_sym_lds(a.n, a.N);
+        if (lds > dev.lds_per_wg_max) return false;
+        auto kern = pcg_resident_sym_kernel<14>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dev.lds_per_wg_max);
+            if (*err != hipSuccess) return true;
+            attr_set = true;
+        }
+        uint32_t grid = (uint32_t)dev.num_cus;  // one workgroup owns a CU's register file and most of its LDS
+        if (grid > a.batch) grid = a.batch;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SymResGeom<14>::THREADS), lds, s, a);
+        *err = hipGetLastError();
+        return true;
+    } else {
+        return false;
+    }
+}
+
+template bool resident_sym_shape<float>(uint32_t, uint32_t);
+template bool resident_sym_shape<double>(uint32_t, uint32_t);
+template bool launch_pcg_resident_sym<float>(const DeviceInfo &, const PcgArgs<float> &, hipStream_t, hipError_t *);
+template bool launch_pcg_resident_sym<double>(const DeviceInfo &, const PcgArgs<double> &, hipStream_t, hipError_t *);
+
+}  // namespace gbdpcg

@@ -13,6 +13,12 @@
 
 namespace gbdpcg {
 
+// The product reads every matrix byte exactly once: stream it with the non-temporal policy.
+#ifndef GBDPCG_SPMV_NT
+#define GBDPCG_SPMV_NT 1
+#endif
+constexpr bool kSpmvNT = GBDPCG_SPMV_NT != 0;
+
 template <typename T, int NCT, int V, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_t rpw, uint32_t chunks)
 {
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmv_kernel(SpmvArgs<T> a, uint32_
     const LaneMap<NCT, V> m(n, lane);
     const StreamCtx<T, NCT, V> cx(m, lane);
     const T *M = a.M + (size_t)prob * 3 * n * n * N;
-    RowStream<T, NCT, V> rs;
+    RowStream<T, NCT, V, kSpmvNT> rs;
     rs.prime(M, k0 + wave, k1, WAVES, cx, n);
 
     // halo window [x_{k0-1} .. x_{k1}] with zeros outside the vector
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmv_sym_kernel(SpmvArgs<T> a, uin
     const size_t len = (size_t)n * N;
 
     const SymCtx<T, NCT> cx(lane);
-    SymStream<T, NCT> ss;
+    SymStream<T, NCT, kSpmvNT> ss;
     const uint32_t first = k0 ? k0 - 1 : 0u;
     ss.prime(a.M + (size_t)prob * 3 * n * n * N, first + wave, k1, WAVES, cx);
 

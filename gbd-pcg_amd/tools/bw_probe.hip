@@ -62,6 +62,59 @@ __global__ __launch_bounds__(256) void read2_kernel(const float2* __restrict__ p
     if (acc == 123.456f) out[0] = acc;
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// same as read4_slab / read2 with the non-temporal cache policy (global_load ... nt)
+__global__ __launch_bounds__(256) void read4_slab_nt_kernel(const v4f* __restrict__ p, size_t n4, float* out)
+{
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = min(n4, lo + per);
+    float acc = 0.f;
+    size_t i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {
+        v4f a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + 256),
+            c = __builtin_nontemporal_load(p + i + 512), d = __builtin_nontemporal_load(p + i + 768);
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+    }
+    for (; i < hi; i += 256) { v4f a = p[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+template <bool NT, bool SWEEP>
+__global__ __launch_bounds__(256) void read2x_kernel(const v2f* __restrict__ p, size_t n2, float* out)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t waves = (size_t)gridDim.x * 4;
+    const size_t pieces = n2 / 63;
+    const size_t gw = (size_t)blockIdx.x * 4 + wave;
+    float acc = 0.f;
+    auto ld = [&](size_t piece) -> v2f {
+        const v2f* q = p + piece * 63 + lane;
+        if (NT) return __builtin_nontemporal_load(q);
+        return *q;
+    };
+    if (lane < 63) {
+        if (SWEEP) {
+            // chip-wide in-order sweep: in round i the waves read 5*waves adjacent pieces
+            for (size_t base = gw * 5; base + 4 < pieces; base += waves * 5) {
+                v2f a = ld(base), b = ld(base + 1), c = ld(base + 2), d = ld(base + 3), e = ld(base + 4);
+                acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y + e.x + e.y;
+            }
+        } else {
+            const size_t per = (pieces + waves - 1) / waves;
+            size_t piece = gw * per;
+            const size_t end = min(pieces, piece + per);
+            for (; piece + 4 < end; piece += 5) {
+                v2f a = ld(piece), b = ld(piece + 1), c = ld(piece + 2), d = ld(piece + 3), e = ld(piece + 4);
+                acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y + e.x + e.y;
+            }
+            for (; piece < end; ++piece) { v2f a = ld(piece); acc += a.x + a.y; }
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
 static float median(std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv)
@@ -94,8 +147,8 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipStream_t s = nullptr;
 
-    const int NV = 5;
-    const char* names[NV] = {"read4 (grid-stride)", "read4 (slab/WG)", "read2 63-lane", "spmv C-ABI", "read4 2048 WG"};
+    const int NV = 10;
+    const char* names[NV] = {"read4 (grid-stride)", "read4 (slab/WG)", "read2 63-lane", "spmv C-ABI", "read4 2048 WG", "read4 slab nt", "read2 63-lane nt", "read2 sweep", "read2 sweep nt", "read2 sweep 4096WG"};
     std::vector<float> t[NV];
     int turn = 0;
     for (int r = 0; r < reps + 3; ++r) {
@@ -108,6 +161,11 @@ int main(int argc, char** argv)
             case 2: hipLaunchKernelGGL(read2_kernel, dim3(256 * 8), dim3(256), 0, s, (const float2*)Mb, melems / 2, out); break;
             case 3: if (gbdpcg_spmv_f32(h, n, N, batch, Mb, x, y, s) != GBDPCG_OK) { printf("spmv failed\n"); return 1; } break;
             case 4: hipLaunchKernelGGL(read4_kernel, dim3(2048), dim3(256), 0, s, (const float4*)Mb, melems / 4, out); break;
+            case 5: hipLaunchKernelGGL(read4_slab_nt_kernel, dim3(256 * 8), dim3(256), 0, s, (const v4f*)Mb, melems / 4, out); break;
+            case 6: hipLaunchKernelGGL((read2x_kernel<true, false>), dim3(256 * 8), dim3(256), 0, s, (const v2f*)Mb, melems / 2, out); break;
+            case 7: hipLaunchKernelGGL((read2x_kernel<false, true>), dim3(256 * 8), dim3(256), 0, s, (const v2f*)Mb, melems / 2, out); break;
+            case 8: hipLaunchKernelGGL((read2x_kernel<true, true>), dim3(256 * 8), dim3(256), 0, s, (const v2f*)Mb, melems / 2, out); break;
+            case 9: hipLaunchKernelGGL((read2x_kernel<false, true>), dim3(256 * 16), dim3(256), 0, s, (const v2f*)Mb, melems / 2, out); break;
             }
             CK(hipEventRecord(e1, s));
             CK(hipEventSynchronize(e1));

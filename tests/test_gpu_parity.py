@@ -383,6 +383,42 @@ def test_symmetric_streaming_solve(solver, orc, dtype, n, N, B):
         assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol
 
 
+@pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (101, 2), (74, 300), (73, 1)])
+def test_symmetric_resident_kernel(solver, orc, N, B):
+    """n = 14, fp32, 72 < N <= 128 with symmetric storage: both matrices stay on one CU for the whole
+    solve (pcg_resident_sym.hip).  L blocks and R_{N-1} are NaN: only [D|R] of rows 0..N-2 and D_{N-1} may
+    be read.  Non-zero initial guess; lambda, the final r and p and the iteration counts against the oracle,
+    once to tolerance and once for a fixed iteration count."""
+    n = 14
+    base = min(B, 6)
+    d = synth.gen_numpy(n, N, seed=900 + N, batch=base, dtype=np.float32)
+    idx = np.arange(B) % base
+    S = d["S"][idx].copy()
+    P = _symmetrize_pinv(n, N, d["Pinv"])[idx].copy()
+    g = (d["gamma"][idx] * (1.0 + 0.01 * np.arange(B))[:, None]).astype(np.float32)
+    lam0 = np.stack([0.1 * synth.normals(950 + b, 0, n * N) for b in range(B)]).astype(np.float32)
+    Sg, Pg = S.reshape(B, N, 3, n * n).copy(), P.reshape(B, N, 3, n * n).copy()
+    for M in (Sg, Pg):
+        M[:, :, 0, :] = np.nan      # every L block
+        M[:, N - 1, 2, :] = np.nan  # R_{N-1}
+    solver.set_symmetric(1)
+    try:
+        for tol, iters in ((1e-6, 60), (0.0, 7)):
+            out = gpu_solve(solver, n, N, B, Sg.reshape(B, -1), Pg.reshape(B, -1), g, lam0=lam0, tol=tol,
+                            max_iter=iters, path=binding.PATH_FUSED)
+            ob = orc.pcg_batch(n, N, B, S, P, g, lambda0=lam0, tol=tol, max_iter=iters)
+            assert np.array_equal(out["iters"], ob["iters"])
+            assert np.array_equal(out["max_iter_exit"], ob["max_iter_exit"].astype(bool))
+            for b in range(0, B, max(1, B // 8)):
+                assert relerr(out["lambda_"][b], ob["lambda_"][b]) < F32_TOL
+                if tol == 0.0:
+                    scale = np.linalg.norm(g[b])
+                    assert np.linalg.norm(out["r"][b] - ob["r"][b]) < 1e-5 * scale
+                    assert np.linalg.norm(out["p"][b] - ob["p"][b]) < 1e-5 * scale
+    finally:
+        solver.set_symmetric(2)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("mode", [0, 2])
 def test_symmetric_auto_mixed_batch(solver, orc, dtype, mode):
