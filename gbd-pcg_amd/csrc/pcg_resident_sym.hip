@@ -33,7 +33,11 @@ template <int NCT> struct SymResGeom {
     static constexpr uint32_t WAVES = 8, GROUPS = 8, SLOTS = 2;
     static constexpr uint32_t THREADS = WAVES * 64;
     static constexpr uint32_t MAX_KNOTS = WAVES * GROUPS * SLOTS;
-    static constexpr uint32_t TILE_LDS_FLOATS = QUADS * THREADS * 4;
+#ifndef GBDPCG_RS_P0Q
+#define GBDPCG_RS_P0Q 2
+#endif
+    static constexpr uint32_t P0_LDS_QUADS = GBDPCG_RS_P0Q;  // leading pieces of the Pinv k0 tile that also live in LDS
+    static constexpr uint32_t TILE_LDS_FLOATS = (QUADS + P0_LDS_QUADS) * THREADS * 4;
 };
 
 // One block-row of one matrix as this lane sees it: q[i] = (M[2rp, 2i], M[2rp+1, 2i], M[2rp, 2i+1], M[2rp+1, 2i+1])
@@ -42,20 +46,37 @@ template <int NCT> struct SymResTile {
     float4 q[SymResGeom<NCT>::QUADS];
 };
 
+// Loading a tile is split in two so that the requests of all four tiles of a problem are in flight
+// together (three tiles, 168 VGPRs, then the fourth; nothing else is live at that point): symres_issue only issues the loads,
+// symres_mask zeroes what must not be used (dead lanes, R_{N-1}) once the data is there.
 template <int NCT>
-__device__ __forceinline__ void symres_load(const float *__restrict__ M, uint32_t N, uint32_t k, uint32_t rp, bool live,
-                                            SymResTile<NCT> &t)
+__device__ __forceinline__ void symres_issue(const float *__restrict__ M, uint32_t k, uint32_t rp, bool live,
+                                             SymResTile<NCT> &t)
 {
     constexpr uint32_t n = NCT;
     const float *src = M + (size_t)(live ? k : 0u) * 3 * n * n + n * n + (live ? rp * 2 : 0u);
-    const bool keep_r = live && k != N - 1;  // R_{N-1} is never used (pcg.cuh:106)
 #pragma unroll
     for (uint32_t i = 0; i < n; ++i) {
         float a[2], b[2];
+#ifdef GBDPCG_RS_TIMING_NOLOAD  // timing experiments only: wrong results
+        a[0] = a[1] = b[0] = b[1] = src == nullptr ? 1.f : 0.f;
+#else
         VecIO<float, 2>::load<true>(src + (2 * i) * n, a);
         VecIO<float, 2>::load<true>(src + (2 * i + 1) * n, b);
+#endif
+        t.q[i] = make_float4(a[0], a[1], b[0], b[1]);
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void symres_mask(uint32_t N, uint32_t k, bool live, SymResTile<NCT> &t)
+{
+    constexpr uint32_t n = NCT;
+    const bool keep_r = live && k != N - 1;  // R_{N-1} is never used (pcg.cuh:106)
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) {
         const bool keep = 2 * i < n ? live : keep_r;
-        t.q[i] = make_float4(keep ? a[0] : 0.f, keep ? a[1] : 0.f, keep ? b[0] : 0.f, keep ? b[1] : 0.f);
+        t.q[i] = make_float4(keep ? t.q[i].x : 0.f, keep ? t.q[i].y : 0.f, keep ? t.q[i].z : 0.f, keep ? t.q[i].w : 0.f);
     }
     // Pin the masked values here: hipcc otherwise sinks the selects to the first use and keeps the raw
     // and the masked copy of every tile alive across the prologue (spills).
@@ -68,42 +89,126 @@ __device__ __forceinline__ void symres_load(const float *__restrict__ M, uint32_
 // The LDS operands are fetched AHEAD steps early and the steps are pinned in source order: left to
 // itself hipcc hoists all 14 + 14 LDS reads to the top (84 VGPRs), which with three resident tiles
 // (168 VGPRs) spills.
-template <int NCT, bool FROM_LDS>
+template <int NCT, uint32_t LQ>
 __device__ __forceinline__ void symres_mv(const SymResTile<NCT> &t, const float4 *lt, const float2 *xk2, float own0,
                                           float own1, float (&acc)[2], float (&tt)[NCT])
 {
     constexpr uint32_t n = NCT;
-    constexpr uint32_t AHEAD = 3;
+#ifndef GBDPCG_RS_AHEAD
+#define GBDPCG_RS_AHEAD 3
+#endif
+    constexpr uint32_t AHEAD = GBDPCG_RS_AHEAD;
     float2 xq[AHEAD + 1];
     float4 vq[AHEAD + 1];
 #pragma unroll
     for (uint32_t i = 0; i < AHEAD; ++i) {
         xq[i] = xk2[i];
-        if (FROM_LDS) vq[i] = lt[i * SymResGeom<NCT>::THREADS];
+        if (i < LQ) vq[i] = lt[i * SymResGeom<NCT>::THREADS];
     }
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f av = {0.f, 0.f};  // (row 2rp, row 2rp+1): one v_pk_fma_f32 per column
+#ifdef GBDPCG_RS_ACC2
+    v2f bv = {0.f, 0.f};
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < n; ++i) {
         if (i + AHEAD < n) {
             xq[(i + AHEAD) % (AHEAD + 1)] = xk2[i + AHEAD];
-            if (FROM_LDS) vq[(i + AHEAD) % (AHEAD + 1)] = lt[(i + AHEAD) * SymResGeom<NCT>::THREADS];
+            if (i + AHEAD < LQ) vq[(i + AHEAD) % (AHEAD + 1)] = lt[(i + AHEAD) * SymResGeom<NCT>::THREADS];
         }
-        const float4 v = FROM_LDS ? vq[i % (AHEAD + 1)] : t.q[i];
+        const float4 v = i < LQ ? vq[i % (AHEAD + 1)] : t.q[i];
         const float2 xv = xq[i % (AHEAD + 1)];
         av = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, av);
+#ifdef GBDPCG_RS_ACC2
+        bv = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, bv);
+#else
         av = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, av);
+#endif
         if (2 * i >= n) {
             tt[2 * i - n] = fma_t(v.y, own1, v.x * own0);
             tt[2 * i - n + 1] = fma_t(v.w, own1, v.z * own0);
         }
         // anchor the step: without it the accumulator chain is sunk below the reduce-scatter and the
         // operands of all 14 steps stay live
+#ifdef GBDPCG_RS_ACC2
+        asm volatile("" : "+v"(av), "+v"(bv) : : "memory");
+#else
         asm volatile("" : "+v"(av) : : "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef GBDPCG_RS_ACC2
+    av += bv;
+#endif
     acc[0] = av.x;
     acc[1] = av.y;
+}
+
+// Both block-rows of the lane in ONE pass over the operand window [x_k0 ; x_k1 ; x_k1+1] (21 pairs):
+//   pairs  0.. 6 (x_k0)   : D_k0
+//   pairs  7..13 (x_k1)   : R_k0 (+ its transposed share tt0) and D_k1    -> two independent FMA chains
+//   pairs 14..20 (x_k1+1) : R_k1 (+ tt1)
+// x_k1 is read once instead of twice, the first seven pairs are requested before anything else (nothing
+// else is live yet), later pairs AHX steps ahead, LDS-resident tile pieces AHT steps ahead.  tt0 is
+// reduce-scattered between the second and the third phase (u0), tt1 by the caller.
+#ifndef GBDPCG_RS_AHX
+#define GBDPCG_RS_AHX 4
+#endif
+#ifndef GBDPCG_RS_AHT
+#define GBDPCG_RS_AHT 3
+#endif
+__device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2]);
+
+template <int NCT, uint32_t LQ0, uint32_t LQ1>
+__device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const float4 *lt0, const SymResTile<NCT> &t1,
+                                           const float4 *lt1, const float2 *xk2, float2 o0, float2 o1, uint32_t lane,
+                                           float (&y0)[2], float (&y1)[2], float (&u0)[2], float (&tt1)[NCT])
+{
+    constexpr uint32_t n = NCT, H = n / 2, STEPS = 3 * H, TH = SymResGeom<NCT>::THREADS;
+    constexpr uint32_t AHX = GBDPCG_RS_AHX, AHT = GBDPCG_RS_AHT;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    float2 xq[STEPS];  // only a sliding window of it is ever live
+    float4 q0[LQ0 > 0 ? LQ0 : 1], q1[n];
+#pragma unroll
+    for (uint32_t j = 0; j < H; ++j) xq[j] = xk2[j];
+#pragma unroll
+    for (uint32_t i = 0; i < LQ0; ++i) q0[i] = lt0[i * TH];
+    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    float tt0[NCT];
+#pragma unroll
+    for (uint32_t j = 0; j < STEPS; ++j) {
+        // requests for later steps
+        if (j >= H - AHX && j + AHX < STEPS && j + AHX >= H) xq[j + AHX] = xk2[j + AHX];
+        if (LQ1 > 0 && j + AHT >= H && j + AHT - H < LQ1) q1[j + AHT - H] = lt1[(j + AHT - H) * TH];
+        const float2 xv = xq[j];
+        if (j < 2 * H) {  // block-row k0, column pair j of [D|R]
+            const float4 v = j < LQ0 ? q0[j] : t0.q[j];
+            a0 = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, a0);
+            a0 = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, a0);
+            if (j >= H) {
+                tt0[2 * (j - H)] = fma_t(v.y, o0.y, v.x * o0.x);
+                tt0[2 * (j - H) + 1] = fma_t(v.w, o0.y, v.z * o0.x);
+            }
+        }
+        if (j >= H) {     // block-row k1, column pair j - H
+            const float4 v = j - H < LQ1 ? q1[j - H] : t1.q[j - H];
+            a1 = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, a1);
+            a1 = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, a1);
+            if (j >= 2 * H) {
+                tt1[2 * (j - 2 * H)] = fma_t(v.y, o1.y, v.x * o1.x);
+                tt1[2 * (j - 2 * H) + 1] = fma_t(v.w, o1.y, v.z * o1.x);
+            }
+        }
+        // anchor the step (see symres_mv)
+        asm volatile("" : "+v"(a0), "+v"(a1) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 2 * H - 1) {
+            symres_reduce_scatter14(tt0, lane, u0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    y0[0] = a0.x; y0[1] = a0.y;
+    y1[0] = a1.x; y1[1] = a1.y;
 }
 
 // Sum tt[c] over the 8 lanes of the aligned group and leave entries 2rp, 2rp+1 in lane rp:
@@ -114,6 +219,11 @@ __device__ __forceinline__ void symres_mv(const SymResTile<NCT> &t, const float4
 #define GBDPCG_DPP_ADD(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2])
 {
+#ifdef GBDPCG_RS_TIMING_NOREDUCE  // timing experiments only: wrong results
+    out[0] = t[0] + t[2] + t[4] + t[6] + t[8] + t[10] + t[12];
+    out[1] = t[1] + t[3] + t[5] + t[7] + t[9] + t[11] + t[13];
+    return;
+#endif
 #define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_half_mirror row_mask:0xf bank_mask:0xf\n"
     asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7) D(8) D(9) D(10) D(11) D(12) D(13)
                  : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
@@ -137,15 +247,20 @@ __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t
 }
 #undef GBDPCG_DPP_ADD
 
-template <int WAVES> __device__ __forceinline__ float symres_wg_sum(float part, float *red, uint32_t lane, uint32_t wave)
+// Pull one 128-byte line of the NEXT problem's matrices towards the Infinity Cache while this problem
+// iterates: every CU finishes its solve at about the same time, so without this all 256 CUs hit HBM
+// with their 401 KB tile loads in the same burst.  The load is an LDS-DMA (no VGPR destination, so
+// nothing the compiler allocates can be clobbered when it lands) into a per-wave dump area of LDS that
+// is never read; it is hidden from hipcc's waitcnt bookkeeping, so no barrier or LDS read waits for it.
+__device__ __forceinline__ void symres_touch(const float *M, size_t bytes, uint32_t line, uint32_t lds_dump)
 {
-    part = wave_sum(part);
-    if (lane == 0) red[wave] = part;
-    __syncthreads();
-    float tot = red[0];
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) tot += red[w];
-    return tot;
+    const uintptr_t first = reinterpret_cast<uintptr_t>(M);
+    uintptr_t addr = (first & ~uintptr_t(127)) + (uintptr_t)line * 128;
+    if (addr >= first + bytes) addr = first;  // past the end: touch the first line again
+    if (addr < first) addr = first;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(addr), "s"(lds_dump) : "memory");
 }
 
 template <int NCT>
@@ -161,19 +276,25 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t padded = align16<float>((N + 2) * n);
+    const uint32_t padded = align16<float>((N + 3) * n);
     float4 *lt = reinterpret_cast<float4 *>(smem) + tid;  // this lane's column of the LDS-resident tile (Pinv, k1)
+    float4 *lt0 = lt + G::QUADS * G::THREADS;             // ... and of the first pieces of the Pinv k0 tile
     float *xa = smem + G::TILE_LDS_FLOATS, *xb = xa + padded;  // padded mirrors of p (lambda in the prologue) and r
     float *zs = xb + padded;                                   // R_{k-1}^T x_{k-1} for the even block-rows
     float *red0 = zs + padded, *red1 = red0 + WAVES;
     float *ls = red1 + WAVES;                                  // lambda
+    // LDS byte address of this wave's 256-byte dump area for the prefetch loads (symres_touch)
+    const uint32_t dump = (uint32_t)(uintptr_t)(ls + align16<float>(len)) + wave * 256;
 
     const uint32_t rp = lane & 7u;
     const uint32_t k0 = 2 * (wave * G::GROUPS + (lane >> 3)), k1 = k0 + 1;
     const bool live0 = rp < n / 2 && k0 < N, live1 = rp < n / 2 && k1 < N;
     const uint32_t row0 = (live0 ? k0 * n + rp * 2 : 0u), row1 = (live1 ? k1 * n + rp * 2 : 0u);
     // x operand windows inside a padded mirror (n zeros before x_0 and after x_{N-1}); dead lanes read row 0
-    const uint32_t xo0 = n + (live0 ? k0 : 0u) * n, xo1 = n + (live1 ? k1 : 0u) * n;
+    const uint32_t xo0 = n + (live0 ? k0 : 0u) * n;
+#ifdef GBDPCG_RS_TWO_PASS
+    const uint32_t xo1 = n + (live1 ? k1 : 0u) * n;
+#endif
     const uint32_t zo1 = n + (live1 ? k1 + 1 : 0u) * n + rp * 2;  // where this lane's k1 -> k1+1 products go
     const uint32_t zo0 = n + (live0 ? k0 : 0u) * n + rp * 2;      // ... and where the ones for its k0 rows arrive
     const size_t mstride = (size_t)3 * n * n * N;
@@ -189,13 +310,21 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         SymResTile<NCT> s0, s1, p0;
         {
             SymResTile<NCT> p1;
-            symres_load<NCT>(P, N, k1, rp, live1, p1);
+            symres_issue<NCT>(P, k1, rp, live1, p1);
+            symres_issue<NCT>(S, k0, rp, live0, s0);
+            symres_issue<NCT>(S, k1, rp, live1, s1);
+            __builtin_amdgcn_sched_barrier(0);
+            symres_mask<NCT>(N, k1, live1, p1);
 #pragma unroll
             for (uint32_t i = 0; i < n; ++i) lt[i * G::THREADS] = p1.q[i];
         }
-        symres_load<NCT>(S, N, k0, rp, live0, s0);
-        symres_load<NCT>(S, N, k1, rp, live1, s1);
-        symres_load<NCT>(P, N, k0, rp, live0, p0);
+        symres_issue<NCT>(P, k0, rp, live0, p0);  // takes the registers the LDS-resident tile came through
+        __builtin_amdgcn_sched_barrier(0);
+        symres_mask<NCT>(N, k0, live0, s0);
+        symres_mask<NCT>(N, k1, live1, s1);
+        symres_mask<NCT>(N, k0, live0, p0);
+#pragma unroll
+        for (uint32_t i = 0; i < G::P0_LDS_QUADS; ++i) lt0[i * G::THREADS] = p0.q[i];
 
         for (uint32_t i = tid; i < len; i += G::THREADS) {
             const float l = a.lambda[voff + i];
@@ -203,8 +332,8 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             xa[n + i] = l;
         }
         for (uint32_t i = tid; i < n; i += G::THREADS) {
-            xa[i] = 0.f; xa[n + len + i] = 0.f;
-            xb[i] = 0.f; xb[n + len + i] = 0.f;
+            xa[i] = 0.f; xa[n + len + i] = 0.f; xa[2 * n + len + i] = 0.f;
+            xb[i] = 0.f; xb[n + len + i] = 0.f; xb[2 * n + len + i] = 0.f;
             zs[n + i] = 0.f;  // block-row 0 has nothing above it; never written afterwards
         }
         __syncthreads();
@@ -213,16 +342,31 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         // Leaves y[1] complete and y[0] without the rows' share of R_{k0-1}^T x_{k0-1}, which the previous
         // group puts into zs (GBDPCG_SYMRES_FINISH_Y reads it after the next barrier); PART = the lane's
         // share of x . (M x) INCLUDING what it sent to zs.
-#define GBDPCG_SYMRES_PRODUCT(T0, T1, T1_FROM_LDS, XM, PART)                                                  \
+#ifdef GBDPCG_RS_TIMING_NOLDSTILE  // timing experiments only: wrong results
+#define GBDPCG_RS_P1TILE s1
+#define GBDPCG_RS_P1LQ 0
+#else
+#define GBDPCG_RS_P1TILE p0
+#define GBDPCG_RS_P1LQ n
+#endif
+#ifdef GBDPCG_RS_TWO_PASS
+#define GBDPCG_SYMRES_MV(T0, LQ0, T1, LQ1, XM)                                                                \
+            symres_mv<NCT, LQ0>(T0, lt0, reinterpret_cast<const float2 *>(XM + xo0), o0.x, o0.y, y[0], tt);   \
+            symres_reduce_scatter14(tt, lane, u0);                                                            \
+            symres_mv<NCT, LQ1>(T1, lt, reinterpret_cast<const float2 *>(XM + xo1), o1.x, o1.y, y[1], tt);
+#else
+#define GBDPCG_SYMRES_MV(T0, LQ0, T1, LQ1, XM)                                                                \
+            symres_mv2<NCT, LQ0, LQ1>(T0, lt0, T1, lt, reinterpret_cast<const float2 *>(XM + xo0), o0, o1, lane, \
+                                      y[0], y[1], u0, tt);
+#endif
+#define GBDPCG_SYMRES_PRODUCT(T0, LQ0, T1, LQ1, XM, PART)                                                  \
         {                                                                                                     \
             float tt[NCT], u0[2], u1[2];                                                                      \
             float2 o0 = *reinterpret_cast<const float2 *>(XM + n + row0);                                     \
             float2 o1 = *reinterpret_cast<const float2 *>(XM + n + row1);                                     \
             o0.x = live0 ? o0.x : 0.f; o0.y = live0 ? o0.y : 0.f;                                             \
             o1.x = live1 ? o1.x : 0.f; o1.y = live1 ? o1.y : 0.f;                                             \
-            symres_mv<NCT, false>(T0, nullptr, reinterpret_cast<const float2 *>(XM + xo0), o0.x, o0.y, y[0], tt); \
-            symres_reduce_scatter14(tt, lane, u0);                                                            \
-            symres_mv<NCT, T1_FROM_LDS>(T1, lt, reinterpret_cast<const float2 *>(XM + xo1), o1.x, o1.y, y[1], tt); \
+            GBDPCG_SYMRES_MV(T0, LQ0, T1, LQ1, XM)                                                            \
             symres_reduce_scatter14(tt, lane, u1);                                                            \
             y[1][0] += u0[0];                                                                                 \
             y[1][1] += u0[1];                                                                                 \
@@ -247,44 +391,71 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 
         float y[2][2], part;
         // r = gamma - S lambda                                            (pcg.cuh:118-126)
-        GBDPCG_SYMRES_PRODUCT(s0, s1, false, xa, part)
+        GBDPCG_SYMRES_PRODUCT(s0, 0, s1, 0, xa, part)
         __syncthreads();
         GBDPCG_SYMRES_FINISH_Y()
         if (live0) *xb0 = make_float2(a.gamma[voff + row0] - y[0][0], a.gamma[voff + row0 + 1] - y[0][1]);
         if (live1) *xb1 = make_float2(a.gamma[voff + row1] - y[1][0], a.gamma[voff + row1 + 1] - y[1][1]);
         __syncthreads();
 
+        // Workgroup sum of PART (same order in every thread: the exit branch stays uniform) and the
+        // completion of y[0]; the partials and the zs entries come back in one LDS round trip.
+#define GBDPCG_SYMRES_SUM(RED, TOT)                                                                           \
+        {                                                                                                     \
+            const float ws = wave_sum(part);                                                                  \
+            if (lane == 0) RED[wave] = ws;                                                                    \
+            __syncthreads();                                                                                  \
+            const float4 ra = reinterpret_cast<const float4 *>(RED)[0], rb = reinterpret_cast<const float4 *>(RED)[1]; \
+            GBDPCG_SYMRES_FINISH_Y()                                                                          \
+            TOT = ((ra.x + ra.y) + (ra.z + ra.w)) + ((rb.x + rb.y) + (rb.z + rb.w));                          \
+        }
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
-        GBDPCG_SYMRES_PRODUCT(p0, p0, true, xb, part)
-        float eta = symres_wg_sum<WAVES>(part, red1, lane, wave);
-        GBDPCG_SYMRES_FINISH_Y()
+        GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, GBDPCG_RS_P1TILE, GBDPCG_RS_P1LQ, xb, part)
+        float eta;
+        GBDPCG_SYMRES_SUM(red1, eta)
         if (live0) *xa0 = make_float2(y[0][0], y[0][1]);
         if (live1) *xa1 = make_float2(y[1][0], y[1][1]);
         __syncthreads();
 
+        // prefetch schedule for the next problem of this workgroup: two lines per thread and iteration
+        const uint32_t nprob = prob + gridDim.x;
+        const uint32_t pf_per_matrix = nprob < a.batch ? (uint32_t)((mstride * sizeof(float) + 127) / 128 + G::THREADS) / G::THREADS : 0u;
+        uint32_t pf = 0;
+#define GBDPCG_SYMRES_PREFETCH()                                                                              \
+        if (pf < pf_per_matrix) {                                                                             \
+            symres_touch(a.S + nprob * mstride, mstride * sizeof(float), pf * G::THREADS + tid, dump);        \
+            symres_touch(a.Pinv + nprob * mstride, mstride * sizeof(float), pf * G::THREADS + tid, dump);     \
+            ++pf;                                                                                             \
+        }
+
         uint32_t iter = 0;
         bool max_iter_exit = true;
         for (; iter < a.max_iter; ++iter) {                               // pcg.cuh:154
+            GBDPCG_SYMRES_PREFETCH()
             // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
-            GBDPCG_SYMRES_PRODUCT(s0, s1, false, xa, part)
-            const float alpha = eta / symres_wg_sum<WAVES>(part, red0, lane, wave);
-            GBDPCG_SYMRES_FINISH_Y()
+            GBDPCG_SYMRES_PRODUCT(s0, 0, s1, 0, xa, part)
+            // the lane's own entries of p, lambda, r: requested before the reduction, used after it
+            const float2 pa0 = *xa0, pa1 = *xa1, la0 = *ls0, la1 = *ls1, ra0 = *xb0, ra1 = *xb1;
+            float den;
+            GBDPCG_SYMRES_SUM(red0, den)
+            const float alpha = eta / den;
             // lambda += alpha p ; r -= alpha upsilon                      (pcg.cuh:172-176)
             if (live0) {
-                const float2 pp = *xa0, ll = *ls0, rr = *xb0;
-                *ls0 = make_float2(fma_t(alpha, pp.x, ll.x), fma_t(alpha, pp.y, ll.y));
-                *xb0 = make_float2(fma_t(-alpha, y[0][0], rr.x), fma_t(-alpha, y[0][1], rr.y));
+                *ls0 = make_float2(fma_t(alpha, pa0.x, la0.x), fma_t(alpha, pa0.y, la0.y));
+                *xb0 = make_float2(fma_t(-alpha, y[0][0], ra0.x), fma_t(-alpha, y[0][1], ra0.y));
             }
             if (live1) {
-                const float2 pp = *xa1, ll = *ls1, rr = *xb1;
-                *ls1 = make_float2(fma_t(alpha, pp.x, ll.x), fma_t(alpha, pp.y, ll.y));
-                *xb1 = make_float2(fma_t(-alpha, y[1][0], rr.x), fma_t(-alpha, y[1][1], rr.y));
+                *ls1 = make_float2(fma_t(alpha, pa1.x, la1.x), fma_t(alpha, pa1.y, la1.y));
+                *xb1 = make_float2(fma_t(-alpha, y[1][0], ra1.x), fma_t(-alpha, y[1][1], ra1.y));
             }
+#ifndef GBDPCG_RS_TIMING_NOBAR
             __syncthreads();
+#endif
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            GBDPCG_SYMRES_PRODUCT(p0, p0, true, xb, part)
-            const float eta_new = symres_wg_sum<WAVES>(part, red1, lane, wave);
-            GBDPCG_SYMRES_FINISH_Y()
+            GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, GBDPCG_RS_P1TILE, GBDPCG_RS_P1LQ, xb, part)
+            const float2 pb0 = *xa0, pb1 = *xa1;
+            float eta_new;
+            GBDPCG_SYMRES_SUM(red1, eta_new)
             if (fabsf(eta_new) < a.tol) {                                 // pcg.cuh:195
                 ++iter;
                 max_iter_exit = false;
@@ -292,18 +463,19 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             }
             const float beta = eta_new / eta;                             // pcg.cuh:199-206
             eta = eta_new;
-            if (live0) {
-                const float2 pp = *xa0;
-                *xa0 = make_float2(fma_t(beta, pp.x, y[0][0]), fma_t(beta, pp.y, y[0][1]));
-            }
-            if (live1) {
-                const float2 pp = *xa1;
-                *xa1 = make_float2(fma_t(beta, pp.x, y[1][0]), fma_t(beta, pp.y, y[1][1]));
-            }
+            if (live0) *xa0 = make_float2(fma_t(beta, pb0.x, y[0][0]), fma_t(beta, pb0.y, y[0][1]));
+            if (live1) *xa1 = make_float2(fma_t(beta, pb1.x, y[1][0]), fma_t(beta, pb1.y, y[1][1]));
+#ifndef GBDPCG_RS_TIMING_NOBAR
             __syncthreads();
+#endif
         }
+#undef GBDPCG_SYMRES_SUM
 #undef GBDPCG_SYMRES_PRODUCT
+#undef GBDPCG_SYMRES_MV
 #undef GBDPCG_SYMRES_FINISH_Y
+
+        while (pf < pf_per_matrix) { GBDPCG_SYMRES_PREFETCH() }  // short solves: the rest of the prefetch
+#undef GBDPCG_SYMRES_PREFETCH
 
         // outputs                                                         (pcg.cuh:212,215)
         __syncthreads();
@@ -331,8 +503,8 @@ template <typename T> bool resident_sym_shape(uint32_t n, uint32_t N)
 
 static size_t resident_sym_lds(uint32_t n, uint32_t N)
 {
-    return ((size_t)SymResGeom<14>::TILE_LDS_FLOATS + 3 * (size_t)align16<float>((N + 2) * n) +
-            2 * SymResGeom<14>::WAVES + align16<float>(N * n)) * sizeof(float);
+    return ((size_t)SymResGeom<14>::TILE_LDS_FLOATS + 3 * (size_t)align16<float>((N + 3) * n) +
+            2 * SymResGeom<14>::WAVES + align16<float>(N * n)) * sizeof(float) + SymResGeom<14>::WAVES * 256;
 }
 
 template <typename T>
