@@ -155,8 +155,13 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
                 gbdpcg_status st = ensure_sym_flags(h, batch);
                 if (st != GBDPCG_OK) return st;
             }
-            HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_S, h->sym_flags, false, stream));
-            HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_Pinv, h->sym_flags, true, stream));
+            hipError_t cerr = hipSuccess;
+            if (launch_check_symmetric_pair<T>(n, N, batch, d_S, d_Pinv, h->sym_flags, stream, &cerr)) {
+                HIP_TRY(h, cerr);
+            } else {
+                HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_S, h->sym_flags, false, stream));
+                HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_Pinv, h->sym_flags, true, stream));
+            }
             a.sel = h->sym_flags;
             a.symmetric = true;
             a.want = 1;
@@ -416,6 +421,11 @@ gbdpcg_status gbdpcg_check_symmetric_f32(gbdpcg_handle_t h, uint32_t n, uint32_t
 {
     if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev.device));
+    hipError_t cerr = hipSuccess;
+    if (launch_check_symmetric_pair<float>(n, N, batch, d_M, nullptr, d_flags, (hipStream_t)stream, &cerr)) {
+        HIP_TRY(h, cerr);
+        return GBDPCG_OK;
+    }
     HIP_TRY(h, launch_check_symmetric<float>(h->dev, n, N, batch, d_M, d_flags, false, (hipStream_t)stream));
     return GBDPCG_OK;
 }
@@ -424,6 +434,11 @@ gbdpcg_status gbdpcg_check_symmetric_f64(gbdpcg_handle_t h, uint32_t n, uint32_t
 {
     if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev.device));
+    hipError_t cerr = hipSuccess;
+    if (launch_check_symmetric_pair<double>(n, N, batch, d_M, nullptr, d_flags, (hipStream_t)stream, &cerr)) {
+        HIP_TRY(h, cerr);
+        return GBDPCG_OK;
+    }
     HIP_TRY(h, launch_check_symmetric<double>(h->dev, n, N, batch, d_M, d_flags, false, (hipStream_t)stream));
     return GBDPCG_OK;
 }

@@ -88,6 +88,10 @@ hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *wo
 template <typename T>
 hipError_t launch_check_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *M,
                                   uint8_t *flags, bool and_into, hipStream_t s);
+// S and Pinv in one launch (flags = 1 where both are symmetric); false if the shape does not fit.
+template <typename T>
+bool launch_check_symmetric_pair(uint32_t n, uint32_t N, uint32_t batch, const T *A, const T *B, uint8_t *flags,
+                                 hipStream_t s, hipError_t *err);
 // Does launch_pcg_fused have a symmetric-streaming kernel for this shape (and would it be used)?
 template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
 

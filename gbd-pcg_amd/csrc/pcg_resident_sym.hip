@@ -33,11 +33,17 @@ template <int NCT> struct SymResGeom {
     static constexpr uint32_t WAVES = 8, GROUPS = 8, SLOTS = 2;
     static constexpr uint32_t THREADS = WAVES * 64;
     static constexpr uint32_t MAX_KNOTS = WAVES * GROUPS * SLOTS;
-#ifndef GBDPCG_RS_P0Q
-#define GBDPCG_RS_P0Q 2
-#endif
-    static constexpr uint32_t P0_LDS_QUADS = GBDPCG_RS_P0Q;  // leading pieces of the Pinv k0 tile that also live in LDS
-    static constexpr uint32_t TILE_LDS_FLOATS = (QUADS + P0_LDS_QUADS) * THREADS * 4;
+    static constexpr uint32_t P0_LDS_QUADS = 2;      // leading pieces of the Pinv k0 tile that also live in LDS
+    // One LDS region per 8-lane group: [D_k | R_k] in memory order (2n^2 floats) -- the staging buffer of
+    // the coalesced tile loads; the 8 regions of a wave then hold that wave's share of the Pinv k1 tile.  ROW_PIECES 16-byte pieces are
+    // real, a group loads STG_PIECES (8 lanes x 13); the stride makes the 8 groups of a wave start
+    // 8 banks apart (2-way conflicts at most on the 8-byte reads).
+    static constexpr uint32_t ROW_PIECES = 2 * N_ * N_ / 4, STG_ITERS = (ROW_PIECES + 7) / 8, STG_PIECES = 8 * STG_ITERS;
+    static constexpr uint32_t REGION = 456;
+    static_assert(REGION >= 4 * STG_PIECES && REGION % 64 == 8 && (2 * N_ * N_) % 4 == 0, "region layout");
+    static_assert(GROUPS * REGION >= QUADS * 64 * 4, "a wave's block must hold its LDS-resident tile");
+    static constexpr uint32_t REGIONS_FLOATS = WAVES * GROUPS * REGION;
+    static constexpr uint32_t TILE_LDS_FLOATS = REGIONS_FLOATS + P0_LDS_QUADS * THREADS * 4;
 };
 
 // One block-row of one matrix as this lane sees it: q[i] = (M[2rp, 2i], M[2rp+1, 2i], M[2rp, 2i+1], M[2rp+1, 2i+1])
@@ -46,8 +52,8 @@ template <int NCT> struct SymResTile {
     float4 q[SymResGeom<NCT>::QUADS];
 };
 
-// Loading a tile is split in two so that the requests of all four tiles of a problem are in flight
-// together (three tiles, 168 VGPRs, then the fourth; nothing else is live at that point): symres_issue only issues the loads,
+// Direct tile load (matrix base only 8-byte aligned): every lane reads its own 8-byte pairs.  Split in
+// two so that the requests of three tiles are in flight together: symres_issue only issues the loads,
 // symres_mask zeroes what must not be used (dead lanes, R_{N-1}) once the data is there.
 template <int NCT>
 __device__ __forceinline__ void symres_issue(const float *__restrict__ M, uint32_t k, uint32_t rp, bool live,
@@ -58,12 +64,8 @@ __device__ __forceinline__ void symres_issue(const float *__restrict__ M, uint32
 #pragma unroll
     for (uint32_t i = 0; i < n; ++i) {
         float a[2], b[2];
-#ifdef GBDPCG_RS_TIMING_NOLOAD  // timing experiments only: wrong results
-        a[0] = a[1] = b[0] = b[1] = src == nullptr ? 1.f : 0.f;
-#else
         VecIO<float, 2>::load<true>(src + (2 * i) * n, a);
         VecIO<float, 2>::load<true>(src + (2 * i + 1) * n, b);
-#endif
         t.q[i] = make_float4(a[0], a[1], b[0], b[1]);
     }
 }
@@ -84,64 +86,66 @@ __device__ __forceinline__ void symres_mask(uint32_t N, uint32_t k, bool live, S
     for (uint32_t i = 0; i < n; ++i) asm volatile("" : "+v"(t.q[i].x), "+v"(t.q[i].y), "+v"(t.q[i].z), "+v"(t.q[i].w));
 }
 
-// acc = [D|R] rows of this lane times [x_k; x_{k+1}] (xk2 = 8-byte pairs starting at x_k);
-// tt[c] = R[2rp, c] own0 + R[2rp+1, c] own1, the lane's share of (R^T x_k)[c].
-// The LDS operands are fetched AHEAD steps early and the steps are pinned in source order: left to
-// itself hipcc hoists all 14 + 14 LDS reads to the top (84 VGPRs), which with three resident tiles
-// (168 VGPRs) spills.
-template <int NCT, uint32_t LQ>
-__device__ __forceinline__ void symres_mv(const SymResTile<NCT> &t, const float4 *lt, const float2 *xk2, float own0,
-                                          float own1, float (&acc)[2], float (&tt)[NCT])
+// Coalesced tile load (matrix base 16-byte aligned): the 8 lanes of a group read the 2n^2 contiguous
+// floats of [D_k | R_k] as 16-byte pieces, 128 contiguous bytes per group and instruction (the direct
+// form touches 8 x 56 scattered bytes per instruction and is bound by the texture-address unit), park
+// them in the group's LDS region and pick their own rows up from there.  Wave-local: no barrier.
+// The group regions are written as 16-byte pieces and read back as 8-byte pairs: both through
+// may_alias types, or type-based alias analysis lets hipcc move the reads above the writes.
+typedef float4 __attribute__((may_alias)) float4_alias;
+typedef float2 __attribute__((may_alias)) float2_alias;
+
+template <int NCT> struct SymResStage {
+    float4 b[SymResGeom<NCT>::STG_ITERS];
+};
+template <int NCT>
+__device__ __forceinline__ void symres_stage_issue(const float *__restrict__ M, uint32_t k, bool group_live, uint32_t l8,
+                                                   SymResStage<NCT> &st)
+{
+    using G = SymResGeom<NCT>;
+    constexpr uint32_t n = NCT;
+    const float4 *src = reinterpret_cast<const float4 *>(M + (size_t)(group_live ? k : 0u) * 3 * n * n + n * n);
+#pragma unroll
+    for (uint32_t i = 0; i < G::STG_ITERS; ++i) {
+        const uint32_t piece = l8 + 8 * i;
+        const uint32_t safe = (8 * i + 7 < G::ROW_PIECES || piece < G::ROW_PIECES) ? piece : 0u;  // never past the row
+        const auto v = __builtin_nontemporal_load(reinterpret_cast<const NtVec<float, 4>::type *>(src + safe));
+        st.b[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+}
+// keep_d / keep_r: whether the D / R half may be used at all (dead group, R_{N-1}); zeros are parked otherwise.
+template <int NCT>
+__device__ __forceinline__ void symres_stage_park(const SymResStage<NCT> &st, float *region, uint32_t l8, bool keep_d,
+                                                  bool keep_r)
+{
+    using G = SymResGeom<NCT>;
+    float4_alias *dst = reinterpret_cast<float4_alias *>(region);
+    // Lanes exchange data through the region: the compiler must not move LDS accesses across the
+    // hand-over points just because the addresses of ONE lane do not overlap (the hardware keeps the
+    // LDS operations of a wave in order).
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (uint32_t i = 0; i < G::STG_ITERS; ++i) {
+        const uint32_t piece = l8 + 8 * i;
+        // D_k is pieces [0, n^2/4), R_k the rest (n^2 % 4 == 0 for n = 14)
+        const bool keep = (8 * i + 7 < NCT * NCT / 4) ? keep_d : (8 * i >= NCT * NCT / 4 ? keep_r : (piece < NCT * NCT / 4 ? keep_d : keep_r));
+        const float4 v = st.b[i];
+        dst[piece] = make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+    }
+    asm volatile("" ::: "memory");
+}
+template <int NCT>
+__device__ __forceinline__ void symres_stage_pick(const float *region, uint32_t rp, bool lane_live, SymResTile<NCT> &t)
 {
     constexpr uint32_t n = NCT;
-#ifndef GBDPCG_RS_AHEAD
-#define GBDPCG_RS_AHEAD 3
-#endif
-    constexpr uint32_t AHEAD = GBDPCG_RS_AHEAD;
-    float2 xq[AHEAD + 1];
-    float4 vq[AHEAD + 1];
-#pragma unroll
-    for (uint32_t i = 0; i < AHEAD; ++i) {
-        xq[i] = xk2[i];
-        if (i < LQ) vq[i] = lt[i * SymResGeom<NCT>::THREADS];
-    }
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f av = {0.f, 0.f};  // (row 2rp, row 2rp+1): one v_pk_fma_f32 per column
-#ifdef GBDPCG_RS_ACC2
-    v2f bv = {0.f, 0.f};
-#endif
+    const float2_alias *src = reinterpret_cast<const float2_alias *>(region + rp * 2);
 #pragma unroll
     for (uint32_t i = 0; i < n; ++i) {
-        if (i + AHEAD < n) {
-            xq[(i + AHEAD) % (AHEAD + 1)] = xk2[i + AHEAD];
-            if (i + AHEAD < LQ) vq[(i + AHEAD) % (AHEAD + 1)] = lt[(i + AHEAD) * SymResGeom<NCT>::THREADS];
-        }
-        const float4 v = i < LQ ? vq[i % (AHEAD + 1)] : t.q[i];
-        const float2 xv = xq[i % (AHEAD + 1)];
-        av = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, av);
-#ifdef GBDPCG_RS_ACC2
-        bv = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, bv);
-#else
-        av = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, av);
-#endif
-        if (2 * i >= n) {
-            tt[2 * i - n] = fma_t(v.y, own1, v.x * own0);
-            tt[2 * i - n + 1] = fma_t(v.w, own1, v.z * own0);
-        }
-        // anchor the step: without it the accumulator chain is sunk below the reduce-scatter and the
-        // operands of all 14 steps stay live
-#ifdef GBDPCG_RS_ACC2
-        asm volatile("" : "+v"(av), "+v"(bv) : : "memory");
-#else
-        asm volatile("" : "+v"(av) : : "memory");
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+        const float2 a = src[(2 * i) * n / 2], b = src[(2 * i + 1) * n / 2];
+        t.q[i] = make_float4(lane_live ? a.x : 0.f, lane_live ? a.y : 0.f, lane_live ? b.x : 0.f, lane_live ? b.y : 0.f);
     }
-#ifdef GBDPCG_RS_ACC2
-    av += bv;
-#endif
-    acc[0] = av.x;
-    acc[1] = av.y;
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) asm volatile("" : "+v"(t.q[i].x), "+v"(t.q[i].y), "+v"(t.q[i].z), "+v"(t.q[i].w));
 }
 
 // Both block-rows of the lane in ONE pass over the operand window [x_k0 ; x_k1 ; x_k1+1] (21 pairs):
@@ -151,6 +155,11 @@ __device__ __forceinline__ void symres_mv(const SymResTile<NCT> &t, const float4
 // x_k1 is read once instead of twice, the first seven pairs are requested before anything else (nothing
 // else is live yet), later pairs AHX steps ahead, LDS-resident tile pieces AHT steps ahead.  tt0 is
 // reduce-scattered between the second and the third phase (u0), tt1 by the caller.
+// LQ0 leading pieces of the k0 tile come from LDS (lt0, one float4 per lane and piece, stride THREADS);
+// K1_FROM_LDS: the whole k1 tile is read from LDS (lt1, one float4 per lane and piece, stride 64).
+// The steps are pinned in source order and the accumulators anchored: left to itself hipcc hoists all
+// LDS reads to the top and sinks the accumulator chains below the reduce-scatter, and the operands of
+// every step stay live (with three resident tiles, 168 VGPRs, that spills).
 #ifndef GBDPCG_RS_AHX
 #define GBDPCG_RS_AHX 4
 #endif
@@ -159,9 +168,9 @@ __device__ __forceinline__ void symres_mv(const SymResTile<NCT> &t, const float4
 #endif
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2]);
 
-template <int NCT, uint32_t LQ0, uint32_t LQ1>
+template <int NCT, uint32_t LQ0, bool K1_FROM_LDS>
 __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const float4 *lt0, const SymResTile<NCT> &t1,
-                                           const float4 *lt1, const float2 *xk2, float2 o0, float2 o1, uint32_t lane,
+                                           const float4_alias *lt1, const float2 *xk2, float2 o0, float2 o1, uint32_t lane,
                                            float (&y0)[2], float (&y1)[2], float (&u0)[2], float (&tt1)[NCT])
 {
     constexpr uint32_t n = NCT, H = n / 2, STEPS = 3 * H, TH = SymResGeom<NCT>::THREADS;
@@ -179,7 +188,7 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
     for (uint32_t j = 0; j < STEPS; ++j) {
         // requests for later steps
         if (j >= H - AHX && j + AHX < STEPS && j + AHX >= H) xq[j + AHX] = xk2[j + AHX];
-        if (LQ1 > 0 && j + AHT >= H && j + AHT - H < LQ1) q1[j + AHT - H] = lt1[(j + AHT - H) * TH];
+        if (K1_FROM_LDS && j + AHT >= H && j + AHT - H < n) q1[j + AHT - H] = lt1[(j + AHT - H) * 64];
         const float2 xv = xq[j];
         if (j < 2 * H) {  // block-row k0, column pair j of [D|R]
             const float4 v = j < LQ0 ? q0[j] : t0.q[j];
@@ -191,7 +200,7 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
             }
         }
         if (j >= H) {     // block-row k1, column pair j - H
-            const float4 v = j - H < LQ1 ? q1[j - H] : t1.q[j - H];
+            const float4 v = K1_FROM_LDS ? q1[j - H] : t1.q[j - H];
             a1 = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, a1);
             a1 = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, a1);
             if (j >= 2 * H) {
@@ -199,7 +208,6 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
                 tt1[2 * (j - 2 * H) + 1] = fma_t(v.w, o1.y, v.z * o1.x);
             }
         }
-        // anchor the step (see symres_mv)
         asm volatile("" : "+v"(a0), "+v"(a1) : : "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (j == 2 * H - 1) {
@@ -219,11 +227,6 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
 #define GBDPCG_DPP_ADD(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2])
 {
-#ifdef GBDPCG_RS_TIMING_NOREDUCE  // timing experiments only: wrong results
-    out[0] = t[0] + t[2] + t[4] + t[6] + t[8] + t[10] + t[12];
-    out[1] = t[1] + t[3] + t[5] + t[7] + t[9] + t[11] + t[13];
-    return;
-#endif
 #define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_half_mirror row_mask:0xf bank_mask:0xf\n"
     asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7) D(8) D(9) D(10) D(11) D(12) D(13)
                  : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
@@ -247,23 +250,27 @@ __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t
 }
 #undef GBDPCG_DPP_ADD
 
-// Pull one 128-byte line of the NEXT problem's matrices towards the Infinity Cache while this problem
+// Pull one 128-byte line of the NEXT problem's [D|R] blocks towards the Infinity Cache while this problem
 // iterates: every CU finishes its solve at about the same time, so without this all 256 CUs hit HBM
 // with their 401 KB tile loads in the same burst.  The load is an LDS-DMA (no VGPR destination, so
-// nothing the compiler allocates can be clobbered when it lands) into a per-wave dump area of LDS that
+// nothing the compiler allocates can be clobbered when it lands) into a dump area of LDS that
 // is never read; it is hidden from hipcc's waitcnt bookkeeping, so no barrier or LDS read waits for it.
-__device__ __forceinline__ void symres_touch(const float *M, size_t bytes, uint32_t line, uint32_t lds_dump)
+template <int NCT>
+__device__ __forceinline__ void symres_touch(const float *M, uint32_t N, uint32_t slot, uint32_t lds_dump)
 {
-    const uintptr_t first = reinterpret_cast<uintptr_t>(M);
-    uintptr_t addr = (first & ~uintptr_t(127)) + (uintptr_t)line * 128;
-    if (addr >= first + bytes) addr = first;  // past the end: touch the first line again
-    if (addr < first) addr = first;
+    // slot -> (block-row k, 128-byte step j inside its [D_k | R_k]); L blocks are never touched
+    constexpr uint32_t row_bytes = 2 * NCT * NCT * 4, steps = (row_bytes + 127) / 128 + 1;
+    const uint32_t k = slot / steps, j = slot - k * steps;
+    const uint32_t kk = k < N ? k : 0u;
+    uint32_t off = j * 128;
+    if (off > row_bytes - 4) off = row_bytes - 4;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(M) + ((size_t)kk * 3 * NCT * NCT + NCT * NCT) * 4 + off;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(addr), "s"(lds_dump) : "memory");
 }
 
-template <int NCT>
+template <int NCT, bool STAGED>
 __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 {
     using G = SymResGeom<NCT>;
@@ -277,14 +284,14 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t padded = align16<float>((N + 3) * n);
-    float4 *lt = reinterpret_cast<float4 *>(smem) + tid;  // this lane's column of the LDS-resident tile (Pinv, k1)
-    float4 *lt0 = lt + G::QUADS * G::THREADS;             // ... and of the first pieces of the Pinv k0 tile
+    float *region = smem + (wave * G::GROUPS + (lane >> 3)) * G::REGION;  // this group's LDS region (Pinv k1 lives there)
+    float4 *lt0 = reinterpret_cast<float4 *>(smem + G::REGIONS_FLOATS) + tid;  // first pieces of this lane's Pinv k0 tile
     float *xa = smem + G::TILE_LDS_FLOATS, *xb = xa + padded;  // padded mirrors of p (lambda in the prologue) and r
     float *zs = xb + padded;                                   // R_{k-1}^T x_{k-1} for the even block-rows
     float *red0 = zs + padded, *red1 = red0 + WAVES;
     float *ls = red1 + WAVES;                                  // lambda
-    // LDS byte address of this wave's 256-byte dump area for the prefetch loads (symres_touch)
-    const uint32_t dump = (uint32_t)(uintptr_t)(ls + align16<float>(len)) + wave * 256;
+    // LDS byte address of the 256-byte dump area of the prefetch loads (symres_touch), shared by all waves
+    const uint32_t dump = (uint32_t)(uintptr_t)(ls + align16<float>(len));
 
     const uint32_t rp = lane & 7u;
     const uint32_t k0 = 2 * (wave * G::GROUPS + (lane >> 3)), k1 = k0 + 1;
@@ -292,9 +299,8 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     const uint32_t row0 = (live0 ? k0 * n + rp * 2 : 0u), row1 = (live1 ? k1 * n + rp * 2 : 0u);
     // x operand windows inside a padded mirror (n zeros before x_0 and after x_{N-1}); dead lanes read row 0
     const uint32_t xo0 = n + (live0 ? k0 : 0u) * n;
-#ifdef GBDPCG_RS_TWO_PASS
-    const uint32_t xo1 = n + (live1 ? k1 : 0u) * n;
-#endif
+    // the LDS-resident tile (Pinv k1) of this lane: piece i at ltw[64 i], inside the wave's own block of regions
+    float4_alias *ltw = reinterpret_cast<float4_alias *>(smem + wave * G::GROUPS * G::REGION) + lane;
     const uint32_t zo1 = n + (live1 ? k1 + 1 : 0u) * n + rp * 2;  // where this lane's k1 -> k1+1 products go
     const uint32_t zo0 = n + (live0 ? k0 : 0u) * n + rp * 2;      // ... and where the ones for its k0 rows arrive
     const size_t mstride = (size_t)3 * n * n * N;
@@ -308,21 +314,52 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         // Resident for the whole solve: three tiles in registers, the fourth in LDS.  Everything else
         // (lambda, r, p) lives in LDS between the phases; only y crosses a barrier in registers.
         SymResTile<NCT> s0, s1, p0;
-        {
-            SymResTile<NCT> p1;
-            symres_issue<NCT>(P, k1, rp, live1, p1);
-            symres_issue<NCT>(S, k0, rp, live0, s0);
-            symres_issue<NCT>(S, k1, rp, live1, s1);
+        if constexpr (STAGED) {
+            const uint32_t l8 = rp;
+            const bool g0 = k0 < N, g1 = k1 < N;  // whole group alive
+            // all four tiles are requested at once (4 x 52 VGPRs, nothing else is live yet): one memory
+            // round trip per problem instead of one per tile
+            SymResStage<NCT> sa, sb, sc, sd;
+            symres_stage_issue<NCT>(S, k0, g0, l8, sa);
+            symres_stage_issue<NCT>(S, k1, g1, l8, sb);
+            symres_stage_issue<NCT>(P, k0, g0, l8, sc);
+            symres_stage_issue<NCT>(P, k1, g1, l8, sd);
             __builtin_amdgcn_sched_barrier(0);
-            symres_mask<NCT>(N, k1, live1, p1);
+            symres_stage_park<NCT>(sa, region, l8, g0, g0 && k0 != N - 1);
+            symres_stage_pick<NCT>(region, rp, live0, s0);
+            __builtin_amdgcn_sched_barrier(0);
+            symres_stage_park<NCT>(sb, region, l8, g1, g1 && k1 != N - 1);
+            symres_stage_pick<NCT>(region, rp, live1, s1);
+            __builtin_amdgcn_sched_barrier(0);
+            symres_stage_park<NCT>(sc, region, l8, g0, g0 && k0 != N - 1);
+            symres_stage_pick<NCT>(region, rp, live0, p0);
+            __builtin_amdgcn_sched_barrier(0);
+            symres_stage_park<NCT>(sd, region, l8, g1, g1 && k1 != N - 1);
+            {   // the LDS-resident tile: picked up like the others, then put back one float4 per lane and
+                // piece (conflict-free 16-byte reads in the products) over the wave's own staging block
+                SymResTile<NCT> p1;
+                symres_stage_pick<NCT>(region, rp, live1, p1);
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (uint32_t i = 0; i < n; ++i) lt[i * G::THREADS] = p1.q[i];
+                for (uint32_t i = 0; i < n; ++i) ltw[i * 64] = p1.q[i];
+            }
+        } else {
+            {
+                SymResTile<NCT> p1;
+                symres_issue<NCT>(P, k1, rp, live1, p1);
+                symres_issue<NCT>(S, k0, rp, live0, s0);
+                symres_issue<NCT>(S, k1, rp, live1, s1);
+                __builtin_amdgcn_sched_barrier(0);
+                symres_mask<NCT>(N, k1, live1, p1);
+#pragma unroll
+                for (uint32_t i = 0; i < n; ++i) ltw[i * 64] = p1.q[i];
+            }
+            symres_issue<NCT>(P, k0, rp, live0, p0);  // takes the registers the LDS-resident tile came through
+            __builtin_amdgcn_sched_barrier(0);
+            symres_mask<NCT>(N, k0, live0, s0);
+            symres_mask<NCT>(N, k1, live1, s1);
+            symres_mask<NCT>(N, k0, live0, p0);
         }
-        symres_issue<NCT>(P, k0, rp, live0, p0);  // takes the registers the LDS-resident tile came through
-        __builtin_amdgcn_sched_barrier(0);
-        symres_mask<NCT>(N, k0, live0, s0);
-        symres_mask<NCT>(N, k1, live1, s1);
-        symres_mask<NCT>(N, k0, live0, p0);
 #pragma unroll
         for (uint32_t i = 0; i < G::P0_LDS_QUADS; ++i) lt0[i * G::THREADS] = p0.q[i];
 
@@ -342,31 +379,17 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         // Leaves y[1] complete and y[0] without the rows' share of R_{k0-1}^T x_{k0-1}, which the previous
         // group puts into zs (GBDPCG_SYMRES_FINISH_Y reads it after the next barrier); PART = the lane's
         // share of x . (M x) INCLUDING what it sent to zs.
-#ifdef GBDPCG_RS_TIMING_NOLDSTILE  // timing experiments only: wrong results
-#define GBDPCG_RS_P1TILE s1
-#define GBDPCG_RS_P1LQ 0
-#else
-#define GBDPCG_RS_P1TILE p0
-#define GBDPCG_RS_P1LQ n
-#endif
-#ifdef GBDPCG_RS_TWO_PASS
-#define GBDPCG_SYMRES_MV(T0, LQ0, T1, LQ1, XM)                                                                \
-            symres_mv<NCT, LQ0>(T0, lt0, reinterpret_cast<const float2 *>(XM + xo0), o0.x, o0.y, y[0], tt);   \
-            symres_reduce_scatter14(tt, lane, u0);                                                            \
-            symres_mv<NCT, LQ1>(T1, lt, reinterpret_cast<const float2 *>(XM + xo1), o1.x, o1.y, y[1], tt);
-#else
-#define GBDPCG_SYMRES_MV(T0, LQ0, T1, LQ1, XM)                                                                \
-            symres_mv2<NCT, LQ0, LQ1>(T0, lt0, T1, lt, reinterpret_cast<const float2 *>(XM + xo0), o0, o1, lane, \
-                                      y[0], y[1], u0, tt);
-#endif
-#define GBDPCG_SYMRES_PRODUCT(T0, LQ0, T1, LQ1, XM, PART)                                                  \
+#define GBDPCG_SYMRES_MV(T0, LQ0, T1, K1LDS, XM)                                                              \
+            symres_mv2<NCT, LQ0, K1LDS>(T0, lt0, T1, ltw, reinterpret_cast<const float2 *>(XM + xo0), o0, o1, lane, \
+                                        y[0], y[1], u0, tt);
+#define GBDPCG_SYMRES_PRODUCT(T0, LQ0, T1, K1LDS, XM, PART)                                                  \
         {                                                                                                     \
             float tt[NCT], u0[2], u1[2];                                                                      \
             float2 o0 = *reinterpret_cast<const float2 *>(XM + n + row0);                                     \
             float2 o1 = *reinterpret_cast<const float2 *>(XM + n + row1);                                     \
             o0.x = live0 ? o0.x : 0.f; o0.y = live0 ? o0.y : 0.f;                                             \
             o1.x = live1 ? o1.x : 0.f; o1.y = live1 ? o1.y : 0.f;                                             \
-            GBDPCG_SYMRES_MV(T0, LQ0, T1, LQ1, XM)                                                            \
+            GBDPCG_SYMRES_MV(T0, LQ0, T1, K1LDS, XM)                                                            \
             symres_reduce_scatter14(tt, lane, u1);                                                            \
             y[1][0] += u0[0];                                                                                 \
             y[1][1] += u0[1];                                                                                 \
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 
         float y[2][2], part;
         // r = gamma - S lambda                                            (pcg.cuh:118-126)
-        GBDPCG_SYMRES_PRODUCT(s0, 0, s1, 0, xa, part)
+        GBDPCG_SYMRES_PRODUCT(s0, 0, s1, false, xa, part)
         __syncthreads();
         GBDPCG_SYMRES_FINISH_Y()
         if (live0) *xb0 = make_float2(a.gamma[voff + row0] - y[0][0], a.gamma[voff + row0 + 1] - y[0][1]);
@@ -410,7 +433,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             TOT = ((ra.x + ra.y) + (ra.z + ra.w)) + ((rb.x + rb.y) + (rb.z + rb.w));                          \
         }
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
-        GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, GBDPCG_RS_P1TILE, GBDPCG_RS_P1LQ, xb, part)
+        GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, p0, true, xb, part)
         float eta;
         GBDPCG_SYMRES_SUM(red1, eta)
         if (live0) *xa0 = make_float2(y[0][0], y[0][1]);
@@ -419,12 +442,13 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 
         // prefetch schedule for the next problem of this workgroup: two lines per thread and iteration
         const uint32_t nprob = prob + gridDim.x;
-        const uint32_t pf_per_matrix = nprob < a.batch ? (uint32_t)((mstride * sizeof(float) + 127) / 128 + G::THREADS) / G::THREADS : 0u;
+        constexpr uint32_t pf_steps = (2 * n * n * 4 + 127) / 128 + 1;  // 128-byte steps per [D|R] row (symres_touch)
+        const uint32_t pf_per_matrix = nprob < a.batch ? (N * pf_steps + G::THREADS - 1) / G::THREADS : 0u;
         uint32_t pf = 0;
 #define GBDPCG_SYMRES_PREFETCH()                                                                              \
         if (pf < pf_per_matrix) {                                                                             \
-            symres_touch(a.S + nprob * mstride, mstride * sizeof(float), pf * G::THREADS + tid, dump);        \
-            symres_touch(a.Pinv + nprob * mstride, mstride * sizeof(float), pf * G::THREADS + tid, dump);     \
+            symres_touch<NCT>(a.S + nprob * mstride, N, pf * G::THREADS + tid, dump);                         \
+            symres_touch<NCT>(a.Pinv + nprob * mstride, N, pf * G::THREADS + tid, dump);                      \
             ++pf;                                                                                             \
         }
 
@@ -433,7 +457,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         for (; iter < a.max_iter; ++iter) {                               // pcg.cuh:154
             GBDPCG_SYMRES_PREFETCH()
             // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
-            GBDPCG_SYMRES_PRODUCT(s0, 0, s1, 0, xa, part)
+            GBDPCG_SYMRES_PRODUCT(s0, 0, s1, false, xa, part)
             // the lane's own entries of p, lambda, r: requested before the reduction, used after it
             const float2 pa0 = *xa0, pa1 = *xa1, la0 = *ls0, la1 = *ls1, ra0 = *xb0, ra1 = *xb1;
             float den;
@@ -448,11 +472,9 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
                 *ls1 = make_float2(fma_t(alpha, pa1.x, la1.x), fma_t(alpha, pa1.y, la1.y));
                 *xb1 = make_float2(fma_t(-alpha, y[1][0], ra1.x), fma_t(-alpha, y[1][1], ra1.y));
             }
-#ifndef GBDPCG_RS_TIMING_NOBAR
             __syncthreads();
-#endif
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, GBDPCG_RS_P1TILE, GBDPCG_RS_P1LQ, xb, part)
+            GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, p0, true, xb, part)
             const float2 pb0 = *xa0, pb1 = *xa1;
             float eta_new;
             GBDPCG_SYMRES_SUM(red1, eta_new)
@@ -465,9 +487,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             eta = eta_new;
             if (live0) *xa0 = make_float2(fma_t(beta, pb0.x, y[0][0]), fma_t(beta, pb0.y, y[0][1]));
             if (live1) *xa1 = make_float2(fma_t(beta, pb1.x, y[1][0]), fma_t(beta, pb1.y, y[1][1]));
-#ifndef GBDPCG_RS_TIMING_NOBAR
             __syncthreads();
-#endif
         }
 #undef GBDPCG_SYMRES_SUM
 #undef GBDPCG_SYMRES_PRODUCT
@@ -504,7 +524,7 @@ template <typename T> bool resident_sym_shape(uint32_t n, uint32_t N)
 static size_t resident_sym_lds(uint32_t n, uint32_t N)
 {
     return ((size_t)SymResGeom<14>::TILE_LDS_FLOATS + 3 * (size_t)align16<float>((N + 3) * n) +
-            2 * SymResGeom<14>::WAVES + align16<float>(N * n)) * sizeof(float) + SymResGeom<14>::WAVES * 256;
+            2 * SymResGeom<14>::WAVES + align16<float>(N * n)) * sizeof(float) + 256;
 }
 
 template <typename T>
@@ -515,13 +535,16 @@ bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStre
         if ((reinterpret_cast<uintptr_t>(a.S) % 8) || (reinterpret_cast<uintptr_t>(a.Pinv) % 8)) return false;
         const size_t lds = resident_sym_lds(a.n, a.N);
         if (lds > dev.lds_per_wg_max) return false;
-        auto kern = pcg_resident_sym_kernel<14>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        // coalesced 16-byte tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
+        static const bool no_staging = getenv("GBDPCG_RS_DIRECT_LOADS") != nullptr;  // tuning runs only
+        const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
+        auto kern = staged ? pcg_resident_sym_kernel<14, true> : pcg_resident_sym_kernel<14, false>;
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[staged]) {
             *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)dev.lds_per_wg_max);
             if (*err != hipSuccess) return true;
-            attr_set = true;
+            attr_set[staged] = true;
         }
         uint32_t grid = (uint32_t)dev.num_cus;  // one workgroup owns a CU's register file and most of its LDS
         if (grid > a.batch) grid = a.batch;

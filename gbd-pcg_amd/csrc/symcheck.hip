@@ -55,6 +55,80 @@ __global__ __launch_bounds__(kSymThreads) void check_symmetric_kernel(uint32_t n
     if (bad) flags[prob] = 0;
 }
 
+// Fast form for even n and 16-byte aligned matrices: R_k and L_{k+1} are ADJACENT in memory
+// (k*3n^2 + 2n^2 .. (k+1)*3n^2 + n^2), so a pair is one run of 2n^2 elements.  A workgroup reads `ppw`
+// pairs of up to two matrices (S and Pinv in the same launch) with dense non-temporal 16-byte loads that
+// are all in flight together, parks them in LDS and compares R_k(r,c) with L_{k+1}(c,r) there.
+constexpr uint32_t kPairVPT = 4, kPairThreads = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kPairThreads) void check_symmetric_pair_kernel(uint32_t n, uint32_t N, uint32_t ppw,
+                                                                            uint32_t chunks, const T *__restrict__ A,
+                                                                            const T *__restrict__ B,
+                                                                            uint8_t *__restrict__ flags)
+{
+    using V4 = typename NtVec<float, 4>::type;  // 16 bytes, whatever T is
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t nn = n * n, pair = 2 * nn;
+    const uint32_t prob = blockIdx.x / chunks, chunk = blockIdx.x - prob * chunks;
+    const uint32_t k0 = chunk * ppw;
+    const uint32_t pairs = min(ppw, N - 1 - k0);
+    const uint32_t vecs_per_pair = pair * sizeof(T) / 16;
+    const uint32_t total_v = pairs * vecs_per_pair;
+    const size_t mstride = (size_t)3 * nn * N;
+    V4 *bufA = reinterpret_cast<V4 *>(smem_raw), *bufB = bufA + ppw * vecs_per_pair;
+    V4 va[kPairVPT], vb[kPairVPT];
+#pragma unroll
+    for (uint32_t q = 0; q < kPairVPT; ++q) {
+        const uint32_t i = threadIdx.x + q * kPairThreads;
+        const uint32_t ii = i < total_v ? i : 0u;
+        const uint32_t j = ii / vecs_per_pair, v = ii - j * vecs_per_pair;
+        const size_t off = (size_t)prob * mstride + (size_t)(k0 + j) * 3 * nn + 2 * nn;  // R_{k0+j}, then L_{k0+j+1}
+        va[q] = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(A + off) + v);
+        if (B) vb[q] = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(B + off) + v);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kPairVPT; ++q) {
+        const uint32_t i = threadIdx.x + q * kPairThreads;
+        if (i < total_v) {
+            bufA[i] = va[q];
+            if (B) bufB[i] = vb[q];
+        }
+    }
+    __syncthreads();
+    const T *ea = reinterpret_cast<const T *>(bufA), *eb = reinterpret_cast<const T *>(bufB);
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < pairs * nn; i += kPairThreads) {
+        const uint32_t j = i / nn, e = i - j * nn;
+        const uint32_t c = e / n, r = e - c * n;
+        const uint32_t ri = j * pair + e, li = j * pair + nn + r * n + c;  // R_k(r,c) vs L_{k+1}(c,r)
+        bad |= bits_of(ea[ri]) != bits_of(ea[li]);
+        if (B) bad |= bits_of(eb[ri]) != bits_of(eb[li]);
+    }
+    if (bad) flags[prob] = 0;
+}
+
+// Both matrices of a solve in one pass (B may be null).  Returns false when the shape / alignment does
+// not fit the pair kernel; the caller then uses launch_check_symmetric per matrix.
+template <typename T>
+bool launch_check_symmetric_pair(uint32_t n, uint32_t N, uint32_t batch, const T *A, const T *B, uint8_t *flags,
+                                 hipStream_t s, hipError_t *err)
+{
+    const uint32_t nn = n * n;
+    if (n % 2 || N < 2 || (reinterpret_cast<uintptr_t>(A) % 16) || (B && reinterpret_cast<uintptr_t>(B) % 16)) return false;
+    const uint32_t vecs_per_pair = 2 * nn * sizeof(T) / 16;
+    const uint32_t ppw = kPairVPT * kPairThreads / vecs_per_pair;
+    if (ppw == 0) return false;
+    *err = hipMemsetAsync(flags, 1, batch, s);
+    if (*err != hipSuccess) return true;
+    const uint32_t chunks = (N - 1 + ppw - 1) / ppw;
+    const size_t lds = (size_t)2 * ppw * vecs_per_pair * 16;
+    hipLaunchKernelGGL(check_symmetric_pair_kernel<T>, dim3(batch * chunks), dim3(kPairThreads), lds, s, n, N, ppw, chunks,
+                       A, B, flags);
+    *err = hipGetLastError();
+    return true;
+}
+
 // Fallback for blocks too large for the register-staged kernel (n^2 > 2048): plain strided compare.
 template <typename T>
 __global__ __launch_bounds__(256) void check_symmetric_big_kernel(uint32_t n, uint32_t N, const T *__restrict__ M,
@@ -92,6 +166,10 @@ hipError_t launch_check_symmetric(const DeviceInfo &, uint32_t n, uint32_t N, ui
     return hipGetLastError();
 }
 
+template bool launch_check_symmetric_pair<float>(uint32_t, uint32_t, uint32_t, const float *, const float *, uint8_t *,
+                                                 hipStream_t, hipError_t *);
+template bool launch_check_symmetric_pair<double>(uint32_t, uint32_t, uint32_t, const double *, const double *, uint8_t *,
+                                                  hipStream_t, hipError_t *);
 template hipError_t launch_check_symmetric<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const float *, uint8_t *,
                                                   bool, hipStream_t);
 template hipError_t launch_check_symmetric<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const double *,
