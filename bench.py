@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip table)
 HBM_COPY_CEIL_GBPS = 6290.0  # measured float4-copy ceiling, same table
-HBM_COLD_READ_GBPS = 5751.0  # best pure-read kernel on Infinity-Cache-cold data (profiles/r01_bw_probe_cold.txt)
+HBM_COLD_READ_GBPS = 6185.0  # best pure-read kernel (non-temporal loads) on Infinity-Cache-cold data (profiles/r01_bw_probe_cold.txt)
 
 
 def pmc_traffic(kernel_prefix):
