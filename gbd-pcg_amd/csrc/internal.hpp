@@ -37,7 +37,9 @@ template <typename T> struct PcgArgs {
     uint8_t *max_iter_exit;  // [batch], nullable
     bool symmetric = false;  // stream [D|R] only: caller's assertion, or per problem where sel says so
     // Per-problem kernel selection (symmetric AUTO mode): a launch handles problem b only when
-    // sel[b] == want.  sel == nullptr: every problem.
+    // (sel[b] == 1) == (want == 1): flag 1 -> the symmetric launch, anything else -> the general one, so
+    // every problem is taken by exactly one of the two launches whatever the flag holds.  sel == nullptr:
+    // every problem.
     const uint8_t *sel = nullptr;
     uint8_t want = 0;
 };
@@ -88,6 +90,9 @@ hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *wo
 template <typename T>
 hipError_t launch_check_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *M,
                                   uint8_t *flags, bool and_into, hipStream_t s);
+// Device fills as kernels (capturable, arguments travel with the graph node; see symcheck.hip).
+hipError_t launch_fill_bytes(uint8_t *p, uint8_t v, size_t count, hipStream_t s);
+hipError_t launch_fill_words(uint32_t *p, uint32_t v, size_t count, hipStream_t s);
 // S and Pinv in one launch (flags = 1 where both are symmetric); false if the shape does not fit.
 template <typename T>
 bool launch_check_symmetric_pair(uint32_t n, uint32_t N, uint32_t batch, const T *A, const T *B, uint8_t *flags,

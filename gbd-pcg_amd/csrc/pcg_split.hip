@@ -386,7 +386,7 @@ static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, voi
             if (e != hipSuccess) return e;
         }
     }
-    hipError_t e = hipMemsetAsync(sa.done, 0, (size_t)((a.batch + 3) / 4 * 4) * sizeof(uint32_t), s);
+    hipError_t e = launch_fill_words(sa.done, 0u, (size_t)((a.batch + 3) / 4 * 4), s);
     if (e != hipSuccess) return e;
 
     const dim3 grid(sa.chunks * a.batch), block(WAVES * 64);

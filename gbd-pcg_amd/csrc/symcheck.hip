@@ -5,6 +5,33 @@
 
 namespace gbdpcg {
 
+// Plain kernels instead of hipMemsetAsync: memset nodes of a hipGraph that is replayed back to back were
+// observed to write garbage patterns on ROCm 7.2 (several replays in flight on the legacy stream: the
+// flags then read 0 / random and every problem silently took the general path); kernel nodes carry
+// their arguments with the graph.
+__global__ void fill_bytes_kernel(uint8_t *p, uint8_t v, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+__global__ void fill_words_kernel(uint32_t *p, uint32_t v, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+hipError_t launch_fill_bytes(uint8_t *p, uint8_t v, size_t count, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, v, count);
+    return hipGetLastError();
+}
+hipError_t launch_fill_words(uint32_t *p, uint32_t v, size_t count, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, v, count);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ uint32_t bits_of(float v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint64_t bits_of(double v) { return __builtin_bit_cast(uint64_t, v); }
 
@@ -119,7 +146,7 @@ bool launch_check_symmetric_pair(uint32_t n, uint32_t N, uint32_t batch, const T
     const uint32_t vecs_per_pair = 2 * nn * sizeof(T) / 16;
     const uint32_t ppw = kPairVPT * kPairThreads / vecs_per_pair;
     if (ppw == 0) return false;
-    *err = hipMemsetAsync(flags, 1, batch, s);
+    *err = launch_fill_bytes(flags, 1, batch, s);
     if (*err != hipSuccess) return true;
     const uint32_t chunks = (N - 1 + ppw - 1) / ppw;
     const size_t lds = (size_t)2 * ppw * vecs_per_pair * 16;
@@ -150,7 +177,7 @@ hipError_t launch_check_symmetric(const DeviceInfo &, uint32_t n, uint32_t N, ui
                                   bool and_into, hipStream_t s)
 {
     if (!and_into) {
-        hipError_t e = hipMemsetAsync(flags, 1, batch, s);
+        hipError_t e = launch_fill_bytes(flags, 1, batch, s);
         if (e != hipSuccess) return e;
     }
     if (N < 2) return hipSuccess;  // a single knot has no off-diagonal blocks

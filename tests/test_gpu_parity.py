@@ -419,6 +419,37 @@ def test_symmetric_resident_kernel(solver, orc, N, B):
         solver.set_symmetric(2)
 
 
+def test_symmetric_resident_kernel_unaligned(solver, orc):
+    """Matrices that are only 8-byte aligned (a view 2 floats into a buffer) take the resident kernel's
+    direct-load form instead of the coalesced 16-byte one; same answers."""
+    n, N, B = 14, 96, 3
+    d = synth.gen_numpy(n, N, seed=990, batch=B, dtype=np.float32)
+    S, P, g = d["S"], _symmetrize_pinv(n, N, d["Pinv"]), d["gamma"]
+    ob = orc.pcg_batch(n, N, B, S, P, g, tol=1e-6, max_iter=60)
+
+    def shifted(a):
+        buf = torch.zeros(a.size + 2, dtype=torch.float32, device="cuda")
+        v = buf[2:]
+        v.copy_(torch.from_numpy(a.reshape(-1)))
+        assert v.data_ptr() % 16 == 8
+        return v
+
+    dS, dP, dg = shifted(S), shifted(P), dev(g)
+    lam = torch.zeros_like(dg)
+    solver.set_symmetric(1)
+    solver.set_path(binding.PATH_FUSED)
+    try:
+        iters, flags = solver.solve(n, N, B, dS, dP, dg, lam, tol=1e-6, max_iter=60)
+        torch.cuda.synchronize()
+    finally:
+        solver.set_symmetric(2)
+        solver.set_path(binding.PATH_AUTO)
+    assert np.array_equal(iters.cpu().numpy().astype(np.int64), ob["iters"]) and not flags.cpu().numpy().any()
+    lam = lam.cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        assert relerr(lam[b], ob["lambda_"][b]) < F32_TOL
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("mode", [0, 2])
 def test_symmetric_auto_mixed_batch(solver, orc, dtype, mode):

@@ -145,3 +145,38 @@ def test_register_resident_path_limits(solver, orc):
         assert np.array_equal(iters.cpu().numpy(), ob["iters"].astype(np.int32)), N
         for b in range(2):
             assert relerr(lam.cpu().numpy()[b], ob["lambda_"][b]) < 1e-6, N
+
+
+def test_back_to_back_graph_replays_keep_the_symmetric_path(solver):
+    """Replaying the default-mode graph many times without host synchronisation, with other kernels
+    interleaved on the legacy stream, must not change which kernel solves the problems: the symmetry
+    flags are initialised by a kernel node (a hipGraph memset node wrote garbage in exactly this pattern
+    and every problem silently fell back to the general streaming kernel, 4x slower, same answers)."""
+    n, N, B = 14, 128, 512
+    g = synth.gen_torch(n, N, B, "cuda", torch.float32, seed=77)
+    S, gamma = g["S"], g["gamma"]
+    P = solver.form_pinv(n, N, B, S, binding.PINV_STAIR)
+    lam = torch.zeros_like(gamma)
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    graph = solver.graph_solve(n, N, B, S, P, gamma, lam, None, None, 0.0, 10, it, fl)
+
+    def per_replay(sync):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0.record()
+        for _ in range(20):
+            lam.zero_()
+            graph.launch()
+            if sync:
+                torch.cuda.synchronize()
+        t1.record()
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1) / 20
+
+    per_replay(True)
+    synced = per_replay(True)
+    queued = per_replay(False)
+    graph.close()
+    assert int(it.min()) == 10 and int(it.max()) == 10
+    assert queued < 1.5 * synced, (queued, synced)
