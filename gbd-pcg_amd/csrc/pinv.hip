@@ -147,6 +147,8 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_kernel(uint32_t n, ui
 // lane: n v_readlane broadcasts into scalars, then n FMAs per lane -- no LDS, no barrier, the pivot loop
 // fully unrolled so every register index is static.  Same arithmetic, element for element, as the LDS
 // kernel above.  One wavefront per knot, four knots per workgroup.
+__device__ __forceinline__ uint32_t pinv_bits(float v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint64_t pinv_bits(double v) { return __builtin_bit_cast(uint64_t, v); }
 __device__ __forceinline__ float lane_bcast(float v, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -207,10 +209,79 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_reg_kernel(uint32_t N,
     }
 }
 
-// Stair off-diagonal slots for compile-time n: one wavefront per knot, every inner product reads BOTH
-// operands as contiguous pairs from LDS.  D^-1 blocks are exactly symmetric (mirrored by pass 1), so row r
-// of the first factor is its column r; the intermediate W = A*B is stored transposed for the same reason.
-// Operation order is the LDS kernel's ((A*B)*C, q ascending), so both produce the same bits.
+// 2n <= 32: TWO knots per wavefront, one in each 32-lane half (lane c < 2n of a half owns tableau column c), so
+// 28 + 28 of 64 lanes work instead of 28.  A pivot step needs column j of the half's own knot in every lane
+// of that half, which v_readlane cannot give (one scalar per wave): lane j parks its column in LDS and the
+// half reads it back as broadcast 16-byte reads -- 8 LDS instructions per step instead of 14 readlanes per
+// knot, and a third of the VALU instructions per knot.  Same arithmetic, element for element.
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_diag_pair_kernel(uint32_t N, uint64_t knots, const T *__restrict__ S,
+                                                                     T *__restrict__ Pinv, int kind)
+{
+    constexpr uint32_t n = NCT, nn = n * n, NP = (n + 3) / 4 * 4;  // column padded to whole 16-byte pieces (fp32)
+    static_assert(2 * n <= 32, "two knots per wave need 2n lanes per half");
+    __shared__ __attribute__((aligned(16))) T stage_all[4][2][nn];  // D_k^-1 of each half's knot, for the mirrored write-out
+    __shared__ __attribute__((aligned(16))) T bcast_all[4][2][NP];  // the pivot column of the current step
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, half = lane >> 5, l = lane & 31u;
+    const uint64_t knot = ((uint64_t)blockIdx.x * 4 + wave) * 2 + half;
+    const bool alive = knot < knots;
+    T *stage = stage_all[wave][half];
+    T *bc = bcast_all[wave][half];
+    const size_t blk = (size_t)(alive ? knot : 0) * 3 * nn;
+    const T *D = S + blk + nn;
+    T *out = Pinv + blk;
+
+    T col[n];
+#pragma unroll
+    for (uint32_t r = 0; r < n; ++r) {
+        if (l < n) col[r] = (kind == 0 || !alive) ? (r == l ? T(1) : T(0)) : D[l * n + r];
+        else col[r] = (l - n == r) ? T(1) : T(0);
+    }
+    if (kind != 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) {
+            if (l == j) {
+#pragma unroll
+                for (uint32_t r = 0; r < n; ++r) bc[r] = col[r];
+            }
+            group_sync<64>();
+            T cj[n];
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) cj[r] = bc[r];
+            group_sync<64>();  // everyone has the column before step j+1 overwrites it
+            const T piv = T(1) / cj[j];
+            const T pr = col[j] * piv;  // scaled pivot-row entry of this lane's column
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) col[r] = (r == j) ? pr : fma_t(-cj[r], pr, col[r]);
+        }
+    }
+    // lanes n .. 2n-1 of a half hold the columns of D_k^-1; mirror the upper triangle on the way out
+    if (l >= n && l < 2 * n) {
+#pragma unroll
+        for (uint32_t r = 0; r < n; ++r) stage[(l - n) * n + r] = col[r];
+    }
+    group_sync<64>();
+    if (alive) {
+        const uint32_t kk = (uint32_t)(knot % N);
+        for (uint32_t i = l; i < nn; i += 32) {
+            const uint32_t c = i / n, r = i - c * n;
+            out[nn + i] = r <= c ? stage[c * n + r] : stage[r * n + c];
+            // the stair pass overwrites every off-diagonal slot except the two never-read corner blocks
+            if (kind != 2 || kk == 0) out[i] = T(0);
+            if (kind != 2 || kk == N - 1) out[2 * nn + i] = T(0);
+        }
+    }
+}
+
+// Stair off-diagonal slots for compile-time n: one wavefront per knot PAIR (k, k+1), every inner product
+// reads BOTH operands as contiguous pairs from LDS.  The wave of knot k produces the right slot of k,
+// R'_k = -D_k^-1 R_k D_{k+1}^-1, and the left slot of k+1, L'_{k+1} = -D_{k+1}^-1 L_{k+1} D_k^-1, evaluated as
+// the transpose of the same operation sequence with L_{k+1}^T in the place of R_k.  When S is symmetric in
+// storage (L_{k+1} == R_k^T bit for bit, tested here by the wave) the second evaluation would repeat the
+// first one operation for operation, so its result is written as the mirror image of the first: half the
+// work, and Pinv comes out exactly symmetric whenever S is.  D^-1 blocks are exactly symmetric (mirrored by
+// pass 1), so row r of the first factor is its column r; the intermediate W = A*B is stored transposed for the
+// same reason.  Operation order is the LDS kernel's ((A*B)*C, q ascending), so both produce the same bits.
 template <typename T, int NCT>
 __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N, uint64_t knots, const T *__restrict__ S,
                                                                      T *Pinv)
@@ -223,24 +294,36 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
     if (knot >= knots) return;
     T *A = lds[wave], *B = A + nn, *C = B + nn, *Wt = C + nn;
     const uint32_t k = (uint32_t)(knot % N);
-    const size_t blk = (size_t)knot * 3 * nn;
+    if (k == N - 1) return;  // the last knot of a problem has no right neighbour (wave-uniform)
+    const size_t blk = (size_t)knot * 3 * nn, nb = blk + (size_t)3 * nn;
 
-    for (int side = 0; side < 2; ++side) {  // 0: left slot (needs k-1), 1: right slot (needs k+1)
-        if ((side == 0 && k == 0) || (side == 1 && k == N - 1)) continue;  // wave-uniform
-        const size_t nb = side == 0 ? blk - (size_t)3 * nn : blk + (size_t)3 * nn;
-        for (uint32_t i = lane; i < nn; i += 64) {
+    constexpr uint32_t EPL = (nn + 63) / 64;  // elements per lane
+    T lt[EPL];                                // L_{k+1}^T, element for element against R_k
+    bool differs = false;
+#pragma unroll
+    for (uint32_t j = 0; j < EPL; ++j) {
+        const uint32_t i = lane + 64 * j;
+        if (i < nn) {
             const uint32_t c = i / n, r = i - c * n;
-            if (side == 1) {
-                A[i] = Pinv[blk + nn + i];            // D_k^-1
-                B[i] = S[blk + 2 * (size_t)nn + i];   // R_k
-                C[i] = Pinv[nb + nn + i];             // D_{k+1}^-1
-            } else {
-                A[i] = Pinv[nb + nn + i];             // D_{k-1}^-1
-                B[i] = S[blk + (size_t)r * n + c];    // L_k^T : element (r,c) = L_k(c,r)
-                C[i] = Pinv[blk + nn + i];            // D_k^-1
-            }
+            const T rk = S[blk + 2 * (size_t)nn + i];  // R_k(r,c)
+            lt[j] = S[nb + (size_t)r * n + c];         // L_{k+1}(c,r)
+            differs |= pinv_bits(rk) != pinv_bits(lt[j]);
+            A[i] = Pinv[blk + nn + i];                 // D_k^-1
+            B[i] = rk;
+            C[i] = Pinv[nb + nn + i];                  // D_{k+1}^-1
         }
-        group_sync<64>();
+    }
+    const bool symmetric = __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
+    group_sync<64>();
+    for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
+        if (pass == 1) {  // general S: the left slot of k+1 from its own data
+#pragma unroll
+            for (uint32_t j = 0; j < EPL; ++j) {
+                const uint32_t i = lane + 64 * j;
+                if (i < nn) B[i] = lt[j];
+            }
+            group_sync<64>();
+        }
         for (uint32_t i = lane; i < nn; i += 64) {
             const uint32_t c = i / n, r = i - c * n;
             // W(r,c) = sum_q A(r,q) B(q,c);  A symmetric: A(r,q) = A(q,r) = A[r*n + q]
@@ -275,8 +358,8 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
 #pragma unroll
                 for (uint32_t q = 0; q < n; ++q) acc = fma_t(Wt[r * n + q], C[c * n + q], acc);
             }
-            if (side == 1) Pinv[blk + 2 * (size_t)nn + i] = -acc;                  // R'_k(r,c)
-            else Pinv[blk + (size_t)r * n + c] = -acc;                             // L'_k(c,r) = X(r,c)
+            if (pass == 0) Pinv[blk + 2 * (size_t)nn + i] = -acc;                 // R'_k(r,c)
+            if (pass == 1 || symmetric) Pinv[nb + (size_t)r * n + c] = -acc;      // L'_{k+1}(c,r) = X(r,c)
         }
         group_sync<64>();
     }
@@ -335,8 +418,13 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
         if (n == NN) {                                                                                               \
             const uint64_t knots = (uint64_t)N * batch, blocks = (knots + 3) / 4;                                    \
             if (blocks > 0x7fffffffull) return hipErrorInvalidValue;                                                 \
-            hipLaunchKernelGGL((pinv_diag_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, S, \
-                               Pinv, kind);                                                                          \
+            if constexpr (2 * NN <= 32) {                                                                            \
+                hipLaunchKernelGGL((pinv_diag_pair_kernel<T, NN>), dim3((uint32_t)((knots + 7) / 8)), dim3(kPinvThreads), 0, s, \
+                                   N, knots, S, Pinv, kind);                                                         \
+            } else {                                                                                                 \
+                hipLaunchKernelGGL((pinv_diag_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, \
+                                   S, Pinv, kind);                                                                   \
+            }                                                                                                        \
             if (kind != 2) return hipGetLastError();                                                                 \
             hipLaunchKernelGGL((pinv_stair_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, S, \
                                Pinv);                                                                                \

@@ -313,6 +313,29 @@ def test_form_pinv(solver, dtype, kind):
     assert relerr(P, want) < (1e-12 if dtype == np.float64 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_form_pinv_general_S(solver, dtype):
+    """The stair of a NON-symmetric S: the device evaluates the left slot of a knot from L_{k+1} itself whenever
+    it is not the mirror image of R_k (the mirror shortcut is for symmetric storage only).  One problem keeps
+    symmetric storage, the others get perturbed L blocks."""
+    n, N, B = 14, 9, 3
+    d = synth.gen_numpy(n, N, seed=43, batch=B, dtype=np.float64)
+    L, D, R = (np.array(x) for x in synth.unpack_bt(n, N, d["S"]))
+    L[1, 4] *= 1.25
+    L[2, 1:] += 0.01 * np.arange(n)[None, :, None]
+    S = synth.pack_bt(L, D, R).astype(dtype)
+    Lq, Dq, Rq = (np.array(x, dtype=np.float64) for x in synth.unpack_bt(n, N, S))
+    want = synth.pack_bt(*synth.stair_pinv_blocks(Lq, Dq, Rq)).reshape(B, N, 3, n * n).copy()
+    P = solver.form_pinv(n, N, B, dev(S), binding.PINV_STAIR)
+    torch.cuda.synchronize()
+    assert solver.check_symmetric(n, N, B, P).cpu().numpy().tolist() == [1, 0, 0]
+    P = P.cpu().numpy().astype(np.float64).reshape(B, N, 3, n * n).copy()
+    for arr in (P, want):
+        arr[:, 0, 0] = 0
+        arr[:, -1, 2] = 0
+    assert relerr(P, want) < (1e-12 if dtype == np.float64 else 1e-5)
+
+
 def test_full_size_config3_properties(solver):
     """BASELINE config 3 at full size (n=14, N=128, batch=1024, fp32): every problem converges in
     the generator's 9-10 iterations and the true residual ||gamma - S lambda|| / ||gamma|| is at
