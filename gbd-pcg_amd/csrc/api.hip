@@ -22,6 +22,8 @@ struct gbdpcg_context {
     uint8_t *d_exit = nullptr;
     uint32_t *h_iters = nullptr;  // pinned
     uint8_t *h_exit = nullptr;    // pinned
+    uint32_t *h_done = nullptr;   // pinned, device-visible: problems that reported convergence (blocking split solves)
+    uint32_t *h_done_dev = nullptr;
     // split-path workspace, grown on demand outside capture
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -136,7 +138,7 @@ gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
 template <typename T>
 gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S, const T *d_Pinv,
                          const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
-                         uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream)
+                         uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream, bool blocking = false)
 {
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
@@ -183,7 +185,14 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
             gbdpcg_status st = ensure_ws(h, need);
             if (st != GBDPCG_OK) return st;
         }
-        HIP_TRY(h, launch_pcg_split<T>(h->dev, a, h->ws, stream));
+        const volatile uint32_t *poll = nullptr;
+        if (blocking && h->h_done_dev) {  // the caller synchronises before returning: nobody else bumps the counter
+            h->h_done[0] = 0;  // problems that converged
+            h->h_done[1] = 0;  // iterations the device has started
+            a.host_done = h->h_done_dev;
+            poll = h->h_done;
+        }
+        HIP_TRY(h, launch_pcg_split<T>(h->dev, a, h->ws, stream, poll));
     }
     return GBDPCG_OK;
 }
@@ -209,7 +218,7 @@ gbdpcg_status solve_blocking_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, con
     if (!h) return GBDPCG_ERR_INVALID;
     hipStream_t s = nullptr;  // the reference launches on the default stream (interface.cuh:132)
     gbdpcg_status st =
-        solve_impl<T>(h, n, N, 1, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, h->d_iters, h->d_exit, s);
+        solve_impl<T>(h, n, N, 1, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, h->d_iters, h->d_exit, s, true);
     if (st != GBDPCG_OK) return st;
     HIP_TRY(h, hipMemcpyAsync(h->h_iters, h->d_iters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(h->h_exit, h->d_exit, sizeof(uint8_t), hipMemcpyDeviceToHost, s));
@@ -357,7 +366,8 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
     if (e == hipSuccess) {
         h->d_exit = reinterpret_cast<uint8_t *>(h->d_iters) + 128;
-        e = hipHostMalloc(reinterpret_cast<void **>(&h->h_iters), 256, hipHostMallocDefault);
+        // coherent (fine-grained) mapping: the device-side bump of h_done must reach the host while the stream still runs
+        e = hipHostMalloc(reinterpret_cast<void **>(&h->h_iters), 256, hipHostMallocCoherent | hipHostMallocMapped);
     }
     if (e != hipSuccess) {
         if (h->d_iters) (void)hipFree(h->d_iters);
@@ -365,6 +375,8 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
         return GBDPCG_ERR_HIP;
     }
     h->h_exit = reinterpret_cast<uint8_t *>(h->h_iters) + 128;
+    h->h_done = h->h_iters + 16;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h->h_done_dev), h->h_done, 0) != hipSuccess) h->h_done_dev = nullptr;
     *out = h;
     return GBDPCG_OK;
 }

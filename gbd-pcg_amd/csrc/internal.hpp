@@ -42,6 +42,9 @@ template <typename T> struct PcgArgs {
     // every problem.
     const uint8_t *sel = nullptr;
     uint8_t want = 0;
+    // Split path, blocking entry points only: a counter in host-visible memory that a problem bumps when
+    // it converges, so that the host can stop enqueueing iteration launches (nullptr: not used).
+    uint32_t *host_done = nullptr;
 };
 
 // Widest per-lane vector (in elements) usable for this block size and these base pointers:
@@ -83,7 +86,8 @@ bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStre
 // ---- pcg_split.hip : many workgroups per problem, two launches per iteration
 template <typename T> size_t split_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
 template <typename T>
-hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s);
+hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,
+                            const volatile uint32_t *host_done_poll = nullptr);
 
 // ---- symcheck.hip : flags[b] = 1 iff L_{k+1} == R_k^T bit for bit for every k of problem b
 // and_into: flags[b] &= result instead of flags[b] = result (second matrix of a pair).

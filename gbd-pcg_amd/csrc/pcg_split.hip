@@ -140,6 +140,9 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
     const uint32_t chunk = blockIdx.x - prob * sa.chunks;
     const uint32_t k0 = chunk * sa.rpw, k1 = min(N, k0 + sa.rpw);
 
+    // progress beacon for the blocking host loop (launch_split_v): the direction launch of iteration `iter` has started
+    if (PHASE == PH_DIRECTION && a.host_done && blockIdx.x == 0 && tid == 0)
+        __hip_atomic_store(a.host_done + 1, (uint32_t)iter + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (PHASE != PH_INIT_R && sa.done[prob]) return;
 
     // matrix loads first: they depend on no vector, so they fly while partials are summed and the
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void pcg_split_kernel(SplitArgs<T
                     sa.done[prob] = 1;
                     a.iters[prob] = (uint32_t)iter;
                     if (a.max_iter_exit) a.max_iter_exit[prob] = 0;
+                    if (a.host_done) __hip_atomic_fetch_add(a.host_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 return;
             }
@@ -350,7 +354,8 @@ __global__ __launch_bounds__(256) void pcg_split_finish(SplitArgs<T> sa, uint32_
 }
 
 template <typename T, int NCT, int V>
-static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s)
+static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,
+                                 const volatile uint32_t *poll)
 {
     constexpr int WAVES = kSplitWaves;
     SplitArgs<T> sa;
@@ -393,6 +398,17 @@ static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, voi
     hipLaunchKernelGGL(k_init, grid, block, lds, s, sa, 0);
     hipLaunchKernelGGL(k_pre, grid, block, lds, s, sa, -1);
     for (uint32_t it = 0; it < a.max_iter; ++it) {
+        // Eager blocking solves are bound by the host's launch rate (3.5 us per launch against 5 us per
+        // iteration on the device): stop enqueueing once every problem has reported convergence.  The
+        // launches skipped would have been no-ops (done[prob] is set), so the result is the same.
+        if (poll) {
+            // ... and never run more than kAhead iterations ahead of the device, or everything is enqueued
+            // long before the first convergence report arrives (poll[1] = last iteration the device started)
+            constexpr uint32_t kAhead = 3;
+            for (uint32_t spins = 0; it >= kAhead && poll[1] + kAhead < it + 1 && poll[0] < a.batch && spins < (1u << 22); ++spins) {
+            }
+            if (poll[0] >= a.batch) break;
+        }
         hipLaunchKernelGGL(k_dir, grid, block, lds, s, sa, (int)it);
         hipLaunchKernelGGL(k_pre, grid, block, lds, s, sa, (int)it);
     }
@@ -403,20 +419,22 @@ static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, voi
 }
 
 template <typename T, int NCT>
-static hipError_t launch_split_n(const DeviceInfo &dev, const PcgArgs<T> &a, void *ws, int V, hipStream_t s)
+static hipError_t launch_split_n(const DeviceInfo &dev, const PcgArgs<T> &a, void *ws, int V, hipStream_t s,
+                                 const volatile uint32_t *poll)
 {
-    if (V == 1) return launch_split_v<T, NCT, 1>(dev, a, ws, s);
+    if (V == 1) return launch_split_v<T, NCT, 1>(dev, a, ws, s, poll);
     if constexpr (NCT == 0 || NCT % 2 == 0) {
-        if (V == 2) return launch_split_v<T, NCT, 2>(dev, a, ws, s);
+        if (V == 2) return launch_split_v<T, NCT, 2>(dev, a, ws, s, poll);
     }
     if constexpr (sizeof(T) == 4 && (NCT == 0 || NCT % 4 == 0)) {
-        if (V == 4) return launch_split_v<T, NCT, 4>(dev, a, ws, s);
+        if (V == 4) return launch_split_v<T, NCT, 4>(dev, a, ws, s, poll);
     }
     return hipErrorInvalidValue;
 }
 
 template <typename T>
-hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s)
+hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,
+                            const volatile uint32_t *poll)
 {
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
@@ -424,16 +442,18 @@ hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *wo
     static const bool generic_only = getenv("GBDPCG_FORCE_GENERIC") != nullptr;  // tuning runs only
     if (!generic_only) {
 #define GBDPCG_CASE(NN) \
-    if (a.n == NN && V == best_v<T, NN>()) return launch_split_v<T, NN, best_v<T, NN>()>(dev, a, workspace, s);
+    if (a.n == NN && V == best_v<T, NN>()) return launch_split_v<T, NN, best_v<T, NN>()>(dev, a, workspace, s, poll);
         GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
 #undef GBDPCG_CASE
     }
-    return launch_split_n<T, 0>(dev, a, workspace, V, s);
+    return launch_split_n<T, 0>(dev, a, workspace, V, s, poll);
 }
 
 template size_t split_workspace_bytes<float>(uint32_t, uint32_t, uint32_t);
 template size_t split_workspace_bytes<double>(uint32_t, uint32_t, uint32_t);
-template hipError_t launch_pcg_split<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t);
-template hipError_t launch_pcg_split<double>(const DeviceInfo &, const PcgArgs<double> &, void *, hipStream_t);
+template hipError_t launch_pcg_split<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t,
+                                            const volatile uint32_t *);
+template hipError_t launch_pcg_split<double>(const DeviceInfo &, const PcgArgs<double> &, void *, hipStream_t,
+                                             const volatile uint32_t *);
 
 }  // namespace gbdpcg
