@@ -4,8 +4,9 @@
 // (n = 14, fp32, N <= 128) when S and Pinv are symmetric in storage (L_{k+1} == R_k^T, tested on the
 // device or asserted by the caller, gbdpcg_set_symmetric).  The symmetric halves [D_k | R_k] of BOTH
 // matrices are 2 * 128 * 2n^2 * 4 B = 401 KB: three quarters live in the registers of one 8-wave
-// workgroup (3 x 56 VGPRs per lane), the last quarter in LDS (114.7 KB), so the matrices are read
-// from HBM ONCE PER SOLVE and an iteration moves no bytes beyond the CU -- the reference's idea of
+// workgroup (3 x 56 VGPRs per lane), the last quarter plus two pieces of the third in LDS (131 KB), the
+// vectors lambda, r, p in LDS too (29 KB), so the matrices are read from HBM ONCE PER SOLVE and an
+// iteration moves no bytes beyond the CU -- the reference's idea of
 // keeping the block-rows next to the ALUs for the whole solve (pcg.cuh:104-110), with the whole
 // problem inside one workgroup so that no grid barrier exists.
 //
@@ -35,9 +36,10 @@ template <int NCT> struct SymResGeom {
     static constexpr uint32_t MAX_KNOTS = WAVES * GROUPS * SLOTS;
     static constexpr uint32_t P0_LDS_QUADS = 2;      // leading pieces of the Pinv k0 tile that also live in LDS
     // One LDS region per 8-lane group: [D_k | R_k] in memory order (2n^2 floats) -- the staging buffer of
-    // the coalesced tile loads; the 8 regions of a wave then hold that wave's share of the Pinv k1 tile.  ROW_PIECES 16-byte pieces are
-    // real, a group loads STG_PIECES (8 lanes x 13); the stride makes the 8 groups of a wave start
-    // 8 banks apart (2-way conflicts at most on the 8-byte reads).
+    // the coalesced tile loads; the 8 regions of a wave then hold that wave's share of the Pinv k1 tile
+    // (one float4 per lane and piece).  ROW_PIECES 16-byte pieces are real, a group loads STG_PIECES
+    // (8 lanes x 13); the stride makes the 8 groups of a wave start 8 banks apart (2-way conflicts at
+    // most on the 8-byte reads of the staging step).
     static constexpr uint32_t ROW_PIECES = 2 * N_ * N_ / 4, STG_ITERS = (ROW_PIECES + 7) / 8, STG_PIECES = 8 * STG_ITERS;
     static constexpr uint32_t REGION = 456;
     static_assert(REGION >= 4 * STG_PIECES && REGION % 64 == 8 && (2 * N_ * N_) % 4 == 0, "region layout");
