@@ -24,6 +24,8 @@ struct gbdpcg_context {
     uint8_t *h_exit = nullptr;    // pinned
     uint32_t *h_done = nullptr;   // pinned, device-visible: problems that reported convergence (blocking split solves)
     uint32_t *h_done_dev = nullptr;
+    uint32_t *h_iters_dev = nullptr;  // device views of h_iters / h_exit: the blocking entry points let the kernels
+    uint8_t *h_exit_dev = nullptr;    // write the two status words straight to the host (no copy-back)
     // split-path workspace, grown on demand outside capture
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -217,11 +219,16 @@ gbdpcg_status solve_blocking_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, con
 {
     if (!h) return GBDPCG_ERR_INVALID;
     hipStream_t s = nullptr;  // the reference launches on the default stream (interface.cuh:132)
-    gbdpcg_status st =
-        solve_impl<T>(h, n, N, 1, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, h->d_iters, h->d_exit, s, true);
+    // status words: written by the kernels straight into coherent pinned host memory when it is mapped
+    // (saves the two copy-backs of interface.cuh:136,141), else into device words that are copied back
+    const bool direct = h->h_iters_dev != nullptr;
+    gbdpcg_status st = solve_impl<T>(h, n, N, 1, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter,
+                                     direct ? h->h_iters_dev : h->d_iters, direct ? h->h_exit_dev : h->d_exit, s, true);
     if (st != GBDPCG_OK) return st;
-    HIP_TRY(h, hipMemcpyAsync(h->h_iters, h->d_iters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(h->h_exit, h->d_exit, sizeof(uint8_t), hipMemcpyDeviceToHost, s));
+    if (!direct) {
+        HIP_TRY(h, hipMemcpyAsync(h->h_iters, h->d_iters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->h_exit, h->d_exit, sizeof(uint8_t), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(h, hipStreamSynchronize(s));  // interface.cuh:136 synchronises through its blocking copy
     if (h_iters) *h_iters = *h->h_iters;
     if (h_exit) *h_exit = *h->h_exit;
@@ -377,6 +384,10 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     h->h_exit = reinterpret_cast<uint8_t *>(h->h_iters) + 128;
     h->h_done = h->h_iters + 16;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h->h_done_dev), h->h_done, 0) != hipSuccess) h->h_done_dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h->h_iters_dev), h->h_iters, 0) == hipSuccess)
+        h->h_exit_dev = reinterpret_cast<uint8_t *>(h->h_iters_dev) + 128;
+    else
+        h->h_iters_dev = nullptr;
     *out = h;
     return GBDPCG_OK;
 }
