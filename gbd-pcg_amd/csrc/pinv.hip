@@ -273,6 +273,75 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_pair_kernel(uint32_t N
     }
 }
 
+// n <= 16: FOUR knots per wavefront, one per 16-lane quarter, with the IN-PLACE form of the same
+// elimination: lane c < n of a quarter owns column c of the n x n block only.  The identity half of the
+// [D | I] tableau is never stored: its column j stays the unit vector e_j until pivot step j (its pivot-row
+// entries are zero up to then) and is created in that step in the place of column j of D, whose pivot-step
+// update would only produce e_j.  So lane j computes (r == j ? piv : fma(-cj[r], piv, 0)) -- exactly what
+// the tableau lane n+j computes from e_j -- and every other lane the usual update: the same floating-point
+// operations on the same numbers as the tableau kernels, with 56 of 64 lanes busy instead of 28.
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_diag_quad_kernel(uint32_t N, uint64_t knots, const T *__restrict__ S,
+                                                                     T *__restrict__ Pinv, int kind)
+{
+    constexpr uint32_t n = NCT, nn = n * n, NP = (n + 3) / 4 * 4;
+    static_assert(n <= 16, "four knots per wave need n lanes per quarter");
+    __shared__ __attribute__((aligned(16))) T stage_all[4][4][nn];  // D_k^-1 of each quarter's knot, for the mirrored write-out
+    __shared__ __attribute__((aligned(16))) T bcast_all[4][4][NP];  // the pivot column of the current step
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, quarter = lane >> 4, l = lane & 15u;
+    const uint64_t knot = ((uint64_t)blockIdx.x * 4 + wave) * 4 + quarter;
+    const bool alive = knot < knots;
+    T *stage = stage_all[wave][quarter];
+    T *bc = bcast_all[wave][quarter];
+    const size_t blk = (size_t)(alive ? knot : 0) * 3 * nn;
+    const T *D = S + blk + nn;
+    const bool owner = l < n;
+
+    T col[n];
+#pragma unroll
+    for (uint32_t r = 0; r < n; ++r) col[r] = (kind == 0 || !alive || !owner) ? (r == l ? T(1) : T(0)) : D[l * n + r];
+    if (kind != 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) {
+            if (l == j) {
+#pragma unroll
+                for (uint32_t r = 0; r < n; ++r) bc[r] = col[r];
+            }
+            group_sync<64>();
+            T cj[n];
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) cj[r] = bc[r];
+            group_sync<64>();  // everyone has the column before step j+1 overwrites it
+            const T piv = T(1) / cj[j];
+            const bool is_j = l == j;
+            const T pr = is_j ? piv : col[j] * piv;  // scaled pivot-row entry of this lane's column
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) col[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+        }
+    }
+    if (owner) {
+#pragma unroll
+        for (uint32_t r = 0; r < n; ++r) stage[l * n + r] = col[r];
+    }
+    group_sync<64>();
+    // write-out by the whole wave: its four knots are consecutive in memory, so the D slots (and, for the
+    // identity / block-Jacobi kinds, the zeroed L and R slots) go out as dense 256-byte stores
+    const uint64_t knot0 = ((uint64_t)blockIdx.x * 4 + wave) * 4;
+    T *out0 = Pinv + (size_t)knot0 * 3 * nn;
+    for (uint32_t e = lane; e < 4 * nn; e += 64) {
+        const uint32_t q = e / nn, i = e - q * nn;
+        if (knot0 + q >= knots) break;
+        const uint32_t c = i / n, r = i - c * n;
+        const T *st = stage_all[wave][q];
+        T *o = out0 + (size_t)q * 3 * nn;
+        o[nn + i] = r <= c ? st[c * n + r] : st[r * n + c];  // mirror the upper triangle: exactly symmetric
+        // the stair pass overwrites every off-diagonal slot except the two never-read corner blocks
+        const uint32_t kk = (uint32_t)((knot0 + q) % N);
+        if (kind != 2 || kk == 0) o[i] = T(0);
+        if (kind != 2 || kk == N - 1) o[2 * nn + i] = T(0);
+    }
+}
+
 // Stair off-diagonal slots for compile-time n: one wavefront per knot PAIR (k, k+1), every inner product
 // reads BOTH operands as contiguous pairs from LDS.  The wave of knot k produces the right slot of k,
 // R'_k = -D_k^-1 R_k D_{k+1}^-1, and the left slot of k+1, L'_{k+1} = -D_{k+1}^-1 L_{k+1} D_k^-1, evaluated as
@@ -324,42 +393,90 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
             }
             group_sync<64>();
         }
-        for (uint32_t i = lane; i < nn; i += 64) {
-            const uint32_t c = i / n, r = i - c * n;
-            // W(r,c) = sum_q A(r,q) B(q,c);  A symmetric: A(r,q) = A(q,r) = A[r*n + q]
-            T acc = T(0);
-            if constexpr (n % 2 == 0) {
-                const P2 *ar = reinterpret_cast<const P2 *>(A + r * n), *bc = reinterpret_cast<const P2 *>(B + c * n);
+        if constexpr (n % 2 == 0 && (n / 2) * (n / 2) <= 64) {
+            // 2 x 2 output tiles, one per lane ((n/2)^2 lanes): two rows of the first factor and two columns of
+            // the second feed four accumulators, half the LDS reads per FMA of the one-element form below
+            // (which is bound by LDS bandwidth); every output still sums q ascending, so the bits are the same.
+            constexpr uint32_t H = n / 2;
+            const uint32_t tr = lane / H, tc = lane - tr * H, r0 = 2 * tr, c0 = 2 * tc;
+            const bool tile = lane < H * H;
+            T w00 = T(0), w01 = T(0), w10 = T(0), w11 = T(0);
+            if (tile) {
+                const P2 *a0 = reinterpret_cast<const P2 *>(A + r0 * n), *a1 = reinterpret_cast<const P2 *>(A + (r0 + 1) * n);
+                const P2 *b0 = reinterpret_cast<const P2 *>(B + c0 * n), *b1 = reinterpret_cast<const P2 *>(B + (c0 + 1) * n);
 #pragma unroll
-                for (uint32_t q = 0; q < n / 2; ++q) {
-                    const P2 a2 = ar[q], b2 = bc[q];
-                    acc = fma_t(a2.x, b2.x, acc);
-                    acc = fma_t(a2.y, b2.y, acc);
+                for (uint32_t q = 0; q < H; ++q) {
+                    const P2 x0 = a0[q], x1 = a1[q], y0 = b0[q], y1 = b1[q];
+                    w00 = fma_t(x0.x, y0.x, w00); w00 = fma_t(x0.y, y0.y, w00);
+                    w01 = fma_t(x0.x, y1.x, w01); w01 = fma_t(x0.y, y1.y, w01);
+                    w10 = fma_t(x1.x, y0.x, w10); w10 = fma_t(x1.y, y0.y, w10);
+                    w11 = fma_t(x1.x, y1.x, w11); w11 = fma_t(x1.y, y1.y, w11);
                 }
-            } else {
-#pragma unroll
-                for (uint32_t q = 0; q < n; ++q) acc = fma_t(A[r * n + q], B[c * n + q], acc);
+                Wt[r0 * n + c0] = w00; Wt[r0 * n + c0 + 1] = w01;            // transposed: row r of W contiguous
+                Wt[(r0 + 1) * n + c0] = w10; Wt[(r0 + 1) * n + c0 + 1] = w11;
             }
-            Wt[r * n + c] = acc;  // transposed: row r of W contiguous
-        }
-        group_sync<64>();
-        for (uint32_t i = lane; i < nn; i += 64) {
-            const uint32_t c = i / n, r = i - c * n;
-            T acc = T(0);
-            if constexpr (n % 2 == 0) {
-                const P2 *wr = reinterpret_cast<const P2 *>(Wt + r * n), *cc = reinterpret_cast<const P2 *>(C + c * n);
+            group_sync<64>();
+            if (tile) {
+                const P2 *a0 = reinterpret_cast<const P2 *>(Wt + r0 * n), *a1 = reinterpret_cast<const P2 *>(Wt + (r0 + 1) * n);
+                const P2 *b0 = reinterpret_cast<const P2 *>(C + c0 * n), *b1 = reinterpret_cast<const P2 *>(C + (c0 + 1) * n);
+                T x00 = T(0), x01 = T(0), x10 = T(0), x11 = T(0);
 #pragma unroll
-                for (uint32_t q = 0; q < n / 2; ++q) {
-                    const P2 w2 = wr[q], c2 = cc[q];
-                    acc = fma_t(w2.x, c2.x, acc);
-                    acc = fma_t(w2.y, c2.y, acc);
+                for (uint32_t q = 0; q < H; ++q) {
+                    const P2 u0 = a0[q], u1 = a1[q], y0 = b0[q], y1 = b1[q];
+                    x00 = fma_t(u0.x, y0.x, x00); x00 = fma_t(u0.y, y0.y, x00);
+                    x01 = fma_t(u0.x, y1.x, x01); x01 = fma_t(u0.y, y1.y, x01);
+                    x10 = fma_t(u1.x, y0.x, x10); x10 = fma_t(u1.y, y0.y, x10);
+                    x11 = fma_t(u1.x, y1.x, x11); x11 = fma_t(u1.y, y1.y, x11);
                 }
-            } else {
-#pragma unroll
-                for (uint32_t q = 0; q < n; ++q) acc = fma_t(Wt[r * n + q], C[c * n + q], acc);
+                if (pass == 0) {  // R'_k(r,c) at column-major c*n + r
+                    T *Rp = Pinv + blk + 2 * (size_t)nn;
+                    Rp[c0 * n + r0] = -x00; Rp[c0 * n + r0 + 1] = -x10;
+                    Rp[(c0 + 1) * n + r0] = -x01; Rp[(c0 + 1) * n + r0 + 1] = -x11;
+                }
+                if (pass == 1 || symmetric) {  // L'_{k+1}(c,r) = X(r,c) at column-major r*n + c
+                    T *Lp = Pinv + nb;
+                    Lp[r0 * n + c0] = -x00; Lp[r0 * n + c0 + 1] = -x01;
+                    Lp[(r0 + 1) * n + c0] = -x10; Lp[(r0 + 1) * n + c0 + 1] = -x11;
+                }
             }
-            if (pass == 0) Pinv[blk + 2 * (size_t)nn + i] = -acc;                 // R'_k(r,c)
-            if (pass == 1 || symmetric) Pinv[nb + (size_t)r * n + c] = -acc;      // L'_{k+1}(c,r) = X(r,c)
+        } else {
+            for (uint32_t i = lane; i < nn; i += 64) {
+                const uint32_t c = i / n, r = i - c * n;
+                // W(r,c) = sum_q A(r,q) B(q,c);  A symmetric: A(r,q) = A(q,r) = A[r*n + q]
+                T acc = T(0);
+                if constexpr (n % 2 == 0) {
+                    const P2 *ar = reinterpret_cast<const P2 *>(A + r * n), *bc = reinterpret_cast<const P2 *>(B + c * n);
+#pragma unroll
+                    for (uint32_t q = 0; q < n / 2; ++q) {
+                        const P2 a2 = ar[q], b2 = bc[q];
+                        acc = fma_t(a2.x, b2.x, acc);
+                        acc = fma_t(a2.y, b2.y, acc);
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < n; ++q) acc = fma_t(A[r * n + q], B[c * n + q], acc);
+                }
+                Wt[r * n + c] = acc;  // transposed: row r of W contiguous
+            }
+            group_sync<64>();
+            for (uint32_t i = lane; i < nn; i += 64) {
+                const uint32_t c = i / n, r = i - c * n;
+                T acc = T(0);
+                if constexpr (n % 2 == 0) {
+                    const P2 *wr = reinterpret_cast<const P2 *>(Wt + r * n), *cc = reinterpret_cast<const P2 *>(C + c * n);
+#pragma unroll
+                    for (uint32_t q = 0; q < n / 2; ++q) {
+                        const P2 w2 = wr[q], c2 = cc[q];
+                        acc = fma_t(w2.x, c2.x, acc);
+                        acc = fma_t(w2.y, c2.y, acc);
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < n; ++q) acc = fma_t(Wt[r * n + q], C[c * n + q], acc);
+                }
+                if (pass == 0) Pinv[blk + 2 * (size_t)nn + i] = -acc;                 // R'_k(r,c)
+                if (pass == 1 || symmetric) Pinv[nb + (size_t)r * n + c] = -acc;      // L'_{k+1}(c,r) = X(r,c)
+            }
         }
         group_sync<64>();
     }
@@ -419,8 +536,14 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
             const uint64_t knots = (uint64_t)N * batch, blocks = (knots + 3) / 4;                                    \
             if (blocks > 0x7fffffffull) return hipErrorInvalidValue;                                                 \
             if constexpr (2 * NN <= 32) {                                                                            \
-                hipLaunchKernelGGL((pinv_diag_pair_kernel<T, NN>), dim3((uint32_t)((knots + 7) / 8)), dim3(kPinvThreads), 0, s, \
-                                   N, knots, S, Pinv, kind);                                                         \
+                static const bool force_pair = getenv("GBDPCG_PINV_PAIR") != nullptr; /* tuning runs only */        \
+                if (NN <= 16 && !force_pair && kind == 2) {                                                          \
+                    hipLaunchKernelGGL((pinv_diag_quad_kernel<T, NN>), dim3((uint32_t)((knots + 15) / 16)),         \
+                                       dim3(kPinvThreads), 0, s, N, knots, S, Pinv, kind);                           \
+                } else {                                                                                             \
+                    hipLaunchKernelGGL((pinv_diag_pair_kernel<T, NN>), dim3((uint32_t)((knots + 7) / 8)),           \
+                                       dim3(kPinvThreads), 0, s, N, knots, S, Pinv, kind);                           \
+                }                                                                                                    \
             } else {                                                                                                 \
                 hipLaunchKernelGGL((pinv_diag_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, \
                                    S, Pinv, kind);                                                                   \
