@@ -442,6 +442,27 @@ def test_symmetric_resident_kernel(solver, orc, N, B):
         solver.set_symmetric(2)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("tol,max_iter", [(1e-6, 0), (1e-6, 1), (1e30, 5), (0.0, 2)])
+def test_symmetric_resident_kernel_iteration_edges(solver, orc, mode, tol, max_iter):
+    """max_iter = 0 / 1, an exit on the very first test, a fixed short run: iteration counts, the max-iter flag and
+    the state left in lambda, r, p follow pcg.cuh:154,195,212 exactly as the oracle does."""
+    n, N, B = 14, 100, 3
+    d = synth.gen_numpy(n, N, seed=5, batch=B, dtype=np.float32)
+    S, P, g = d["S"], _symmetrize_pinv(n, N, d["Pinv"]), d["gamma"]
+    solver.set_symmetric(mode)
+    try:
+        out = gpu_solve(solver, n, N, B, S, P, g, tol=tol, max_iter=max_iter, path=binding.PATH_FUSED)
+    finally:
+        solver.set_symmetric(2)
+    ob = orc.pcg_batch(n, N, B, S, P, g, tol=tol, max_iter=max_iter)
+    assert np.array_equal(out["iters"], ob["iters"])
+    assert np.array_equal(out["max_iter_exit"], ob["max_iter_exit"].astype(bool))
+    scale = np.abs(g).max()
+    for key in ("lambda_", "r", "p"):
+        assert np.abs(out[key] - ob[key]).max() < 1e-5 * scale, key
+
+
 def test_symmetric_resident_kernel_unaligned(solver, orc):
     """Matrices that are only 8-byte aligned (a view 2 floats into a buffer) take the resident kernel's
     direct-load form instead of the coalesced 16-byte one; same answers."""
