@@ -482,6 +482,149 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
     }
 }
 
+// STAIR in ONE launch for n <= 16 (even n): a workgroup inverts the diagonal blocks of 16 consecutive knots of
+// one problem (four per wavefront, pinv_diag_quad_kernel's in-place elimination), keeps the mirrored inverses
+// in LDS and evaluates the 15 stair pairs between them from there -- the D^-1 blocks are neither re-read from
+// memory nor waited for across a launch boundary.  Consecutive workgroups overlap by one knot (inverted
+// twice, written once).  Same operations, same bits as the two-pass form.
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t N, uint32_t chunks, const T *__restrict__ S,
+                                                                       T *__restrict__ Pinv)
+{
+    constexpr uint32_t n = NCT, nn = n * n, NP = (n + 3) / 4 * 4, H = n / 2, PAIRS = 15;
+    static_assert(n <= 16 && n % 2 == 0, "quarter-wave elimination and 2 x 2 tiles");
+    using P2 = typename VecOf<T, 2>::type;
+    __shared__ __attribute__((aligned(16))) T inv[16][nn];      // mirrored D^-1 of knots k0 .. k0+15
+    __shared__ __attribute__((aligned(16))) T bcast_all[16][NP];
+    __shared__ __attribute__((aligned(16))) T work[4][2][nn];   // per wave: B (R_k or L_{k+1}^T) and W^T
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, quarter = lane >> 4, l = lane & 15u;
+    const uint32_t prob = blockIdx.x / chunks, chunk = blockIdx.x - prob * chunks;
+    const uint32_t k0 = chunk * PAIRS;
+    const size_t pbase = (size_t)prob * 3 * nn * N;
+
+    {   // ---- pass 1: invert D_{k0 + slot}, slot = 4 wave + quarter
+        const uint32_t slot = wave * 4 + quarter, k = k0 + slot;
+        const bool alive = k < N, owner = l < n;
+        const T *D = S + pbase + (size_t)(alive ? k : 0) * 3 * nn + nn;
+        T *bc = bcast_all[slot];
+        T col[n];
+#pragma unroll
+        for (uint32_t r = 0; r < n; ++r) col[r] = (!alive || !owner) ? (r == l ? T(1) : T(0)) : D[l * n + r];
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) {
+            if (l == j) {
+#pragma unroll
+                for (uint32_t r = 0; r < n; ++r) bc[r] = col[r];
+            }
+            group_sync<64>();
+            T cj[n];
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) cj[r] = bc[r];
+            group_sync<64>();
+            const T piv = T(1) / cj[j];
+            const bool is_j = l == j;
+            const T pr = is_j ? piv : col[j] * piv;
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) col[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+        }
+        if (owner) {  // mirrored on the way into LDS: element (r, c) with r > c takes the value of (c, r)
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r)
+                if (r <= l) inv[slot][l * n + r] = col[r];       // upper triangle of column l, as computed
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r)
+                if (r < l) inv[slot][r * n + l] = col[r];        // its mirror image: (l, r) := (r, l)
+        }
+    }
+    __syncthreads();
+
+    // ---- D slots (and the two corner blocks nobody reads): this workgroup owns knots k0 .. k0+14, and N-1 if it is the last
+    const uint32_t own_end = (chunk == chunks - 1) ? N : min(N, k0 + PAIRS);
+    for (uint32_t e = threadIdx.x; e < (own_end - k0) * nn; e += kPinvThreads) {
+        const uint32_t q = e / nn, i = e - q * nn, k = k0 + q;
+        T *o = Pinv + pbase + (size_t)k * 3 * nn;
+        o[nn + i] = inv[q][i];
+        if (k == 0) o[i] = T(0);
+        if (k == N - 1) o[2 * nn + i] = T(0);
+    }
+
+    // ---- pass 2: pairs (k, k+1), k = k0 + j, j = wave, wave + 4, ...
+    T *B = work[wave][0], *Wt = work[wave][1];
+    const uint32_t tr = lane / H, tc = lane - tr * H, r0 = 2 * tr, c0 = 2 * tc;
+    const bool tile = lane < H * H;
+    constexpr uint32_t EPL = (nn + 63) / 64;
+    for (uint32_t j = wave; j < PAIRS && k0 + j + 1 < N; j += 4) {
+        const uint32_t k = k0 + j;
+        const T *A = inv[j], *C = inv[j + 1];
+        const size_t blk = pbase + (size_t)k * 3 * nn, nb = blk + (size_t)3 * nn;
+        T lt[EPL];
+        bool differs = false;
+#pragma unroll
+        for (uint32_t q = 0; q < EPL; ++q) {
+            const uint32_t i = lane + 64 * q;
+            if (i < nn) {
+                const uint32_t c = i / n, r = i - c * n;
+                const T rk = S[blk + 2 * (size_t)nn + i];   // R_k(r,c)
+                lt[q] = S[nb + (size_t)r * n + c];          // L_{k+1}(c,r)
+                differs |= pinv_bits(rk) != pinv_bits(lt[q]);
+                B[i] = rk;
+            }
+        }
+        const bool symmetric = __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
+        group_sync<64>();
+        for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
+            if (pass == 1) {
+#pragma unroll
+                for (uint32_t q = 0; q < EPL; ++q) {
+                    const uint32_t i = lane + 64 * q;
+                    if (i < nn) B[i] = lt[q];
+                }
+                group_sync<64>();
+            }
+            if (tile) {
+                const P2 *a0 = reinterpret_cast<const P2 *>(A + r0 * n), *a1 = reinterpret_cast<const P2 *>(A + (r0 + 1) * n);
+                const P2 *b0 = reinterpret_cast<const P2 *>(B + c0 * n), *b1 = reinterpret_cast<const P2 *>(B + (c0 + 1) * n);
+                T w00 = T(0), w01 = T(0), w10 = T(0), w11 = T(0);
+#pragma unroll
+                for (uint32_t q = 0; q < H; ++q) {
+                    const P2 x0 = a0[q], x1 = a1[q], y0 = b0[q], y1 = b1[q];
+                    w00 = fma_t(x0.x, y0.x, w00); w00 = fma_t(x0.y, y0.y, w00);
+                    w01 = fma_t(x0.x, y1.x, w01); w01 = fma_t(x0.y, y1.y, w01);
+                    w10 = fma_t(x1.x, y0.x, w10); w10 = fma_t(x1.y, y0.y, w10);
+                    w11 = fma_t(x1.x, y1.x, w11); w11 = fma_t(x1.y, y1.y, w11);
+                }
+                Wt[r0 * n + c0] = w00; Wt[r0 * n + c0 + 1] = w01;
+                Wt[(r0 + 1) * n + c0] = w10; Wt[(r0 + 1) * n + c0 + 1] = w11;
+            }
+            group_sync<64>();
+            if (tile) {
+                const P2 *a0 = reinterpret_cast<const P2 *>(Wt + r0 * n), *a1 = reinterpret_cast<const P2 *>(Wt + (r0 + 1) * n);
+                const P2 *b0 = reinterpret_cast<const P2 *>(C + c0 * n), *b1 = reinterpret_cast<const P2 *>(C + (c0 + 1) * n);
+                T x00 = T(0), x01 = T(0), x10 = T(0), x11 = T(0);
+#pragma unroll
+                for (uint32_t q = 0; q < H; ++q) {
+                    const P2 u0 = a0[q], u1 = a1[q], y0 = b0[q], y1 = b1[q];
+                    x00 = fma_t(u0.x, y0.x, x00); x00 = fma_t(u0.y, y0.y, x00);
+                    x01 = fma_t(u0.x, y1.x, x01); x01 = fma_t(u0.y, y1.y, x01);
+                    x10 = fma_t(u1.x, y0.x, x10); x10 = fma_t(u1.y, y0.y, x10);
+                    x11 = fma_t(u1.x, y1.x, x11); x11 = fma_t(u1.y, y1.y, x11);
+                }
+                if (pass == 0) {
+                    T *Rp = Pinv + blk + 2 * (size_t)nn;
+                    Rp[c0 * n + r0] = -x00; Rp[c0 * n + r0 + 1] = -x10;
+                    Rp[(c0 + 1) * n + r0] = -x01; Rp[(c0 + 1) * n + r0 + 1] = -x11;
+                }
+                if (pass == 1 || symmetric) {
+                    T *Lp = Pinv + nb;
+                    Lp[r0 * n + c0] = -x00; Lp[r0 * n + c0 + 1] = -x01;
+                    Lp[(r0 + 1) * n + c0] = -x10; Lp[(r0 + 1) * n + c0 + 1] = -x11;
+                }
+            }
+            group_sync<64>();
+        }
+    }
+}
+
 template <typename T, int GT, int EPT_MAX>
 static hipError_t launch_form_pinv_g(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
                                      int kind, hipStream_t s)
@@ -535,6 +678,16 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
         if (n == NN) {                                                                                               \
             const uint64_t knots = (uint64_t)N * batch, blocks = (knots + 3) / 4;                                    \
             if (blocks > 0x7fffffffull) return hipErrorInvalidValue;                                                 \
+            if constexpr (NN <= 16 && NN % 2 == 0) {                                                                 \
+                static const bool two_pass = getenv("GBDPCG_PINV_TWO_PASS") != nullptr; /* tuning runs only */      \
+                if (kind == 2 && N >= 2 && !two_pass) {                                                              \
+                    const uint32_t chunks = (N - 1 + 14) / 15;                                                       \
+                    if ((uint64_t)chunks * batch > 0x7fffffffull) return hipErrorInvalidValue;                       \
+                    hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN>), dim3(chunks * batch), dim3(kPinvThreads), 0, s, N, \
+                                       chunks, S, Pinv);                                                             \
+                    return hipGetLastError();                                                                        \
+                }                                                                                                    \
+            }                                                                                                        \
             if constexpr (2 * NN <= 32) {                                                                            \
                 static const bool force_pair = getenv("GBDPCG_PINV_PAIR") != nullptr; /* tuning runs only */        \
                 if (NN <= 16 && !force_pair && kind == 2) {                                                          \
