@@ -314,6 +314,24 @@ def test_form_pinv(solver, dtype, kind):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,N,B", [(14, 2, 2), (14, 15, 1), (14, 16, 3), (14, 17, 2), (14, 31, 1), (14, 128, 2),
+                                   (8, 20, 2), (12, 33, 1), (16, 47, 2), (6, 5, 2), (13, 18, 1), (36, 4, 1)])
+def test_form_pinv_shapes(solver, dtype, n, N, B):
+    """The stair across the kernel families (fused 16-knot workgroups with their chunk seams at 15 / 16 / 17 knots,
+    register Gauss-Jordan, LDS forms) against the host construction; exact symmetry wherever S is symmetric."""
+    d = synth.gen_numpy(n, N, seed=300 + n + N, batch=B, dtype=dtype)
+    P = solver.form_pinv(n, N, B, dev(d["S"]), binding.PINV_STAIR)
+    torch.cuda.synchronize()
+    assert solver.check_symmetric(n, N, B, P).cpu().numpy().tolist() == [1] * B
+    P = P.cpu().numpy().reshape(B, N, 3, n * n).copy()
+    want = d["Pinv"].reshape(B, N, 3, n * n).copy()
+    for arr in (P, want):
+        arr[:, 0, 0] = 0
+        arr[:, -1, 2] = 0
+    assert relerr(P, want) < (1e-12 if dtype == np.float64 else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_form_pinv_general_S(solver, dtype):
     """The stair of a NON-symmetric S: the device evaluates the left slot of a knot from L_{k+1} itself whenever
     it is not the mirror image of R_k (the mirror shortcut is for symmetric storage only).  One problem keeps
