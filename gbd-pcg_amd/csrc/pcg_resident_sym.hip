@@ -48,8 +48,10 @@ template <int NCT> struct SymResGeom {
     static constexpr uint32_t TILE_LDS_FLOATS = REGIONS_FLOATS + P0_LDS_QUADS * THREADS * 4;
 };
 
-// One block-row of one matrix as this lane sees it: q[i] = (M[2rp, 2i], M[2rp+1, 2i], M[2rp, 2i+1], M[2rp+1, 2i+1])
-// over the 2n columns of [D | R].
+// One block-row of one matrix as this lane sees it: q[i] = (M[2rp, 2i], M[2rp, 2i+1], M[2rp+1, 2i], M[2rp+1, 2i+1])
+// over the 2n columns of [D | R] -- the two columns of a ROW adjacent, so that both the main product (a row
+// pair times the x pair as it comes out of LDS, even and odd columns accumulated apart) and the transposed
+// product (a row pair times one broadcast x entry) are single v_pk_fma_f32 instructions.
 template <int NCT> struct SymResTile {
     float4 q[SymResGeom<NCT>::QUADS];
 };
@@ -68,7 +70,7 @@ __device__ __forceinline__ void symres_issue(const float *__restrict__ M, uint32
         float a[2], b[2];
         VecIO<float, 2>::load<true>(src + (2 * i) * n, a);
         VecIO<float, 2>::load<true>(src + (2 * i + 1) * n, b);
-        t.q[i] = make_float4(a[0], a[1], b[0], b[1]);
+        t.q[i] = make_float4(a[0], b[0], a[1], b[1]);
     }
 }
 
@@ -144,7 +146,7 @@ __device__ __forceinline__ void symres_stage_pick(const float *region, uint32_t 
 #pragma unroll
     for (uint32_t i = 0; i < n; ++i) {
         const float2 a = src[(2 * i) * n / 2], b = src[(2 * i + 1) * n / 2];
-        t.q[i] = make_float4(lane_live ? a.x : 0.f, lane_live ? a.y : 0.f, lane_live ? b.x : 0.f, lane_live ? b.y : 0.f);
+        t.q[i] = make_float4(lane_live ? a.x : 0.f, lane_live ? b.x : 0.f, lane_live ? a.y : 0.f, lane_live ? b.y : 0.f);
     }
 #pragma unroll
     for (uint32_t i = 0; i < n; ++i) asm volatile("" : "+v"(t.q[i].x), "+v"(t.q[i].y), "+v"(t.q[i].z), "+v"(t.q[i].w));
@@ -184,41 +186,44 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
     for (uint32_t j = 0; j < H; ++j) xq[j] = xk2[j];
 #pragma unroll
     for (uint32_t i = 0; i < LQ0; ++i) q0[i] = lt0[i * TH];
-    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    // per block-row and row of the lane: (sum over even columns, sum over odd columns)
+    v2f a00 = {0.f, 0.f}, a01 = {0.f, 0.f}, a10 = {0.f, 0.f}, a11 = {0.f, 0.f};
     float tt0[NCT];
 #pragma unroll
     for (uint32_t j = 0; j < STEPS; ++j) {
         // requests for later steps
         if (j >= H - AHX && j + AHX < STEPS && j + AHX >= H) xq[j + AHX] = xk2[j + AHX];
         if (K1_FROM_LDS && j + AHT >= H && j + AHT - H < n) q1[j + AHT - H] = lt1[(j + AHT - H) * 64];
-        const float2 xv = xq[j];
+        const v2f xv = {xq[j].x, xq[j].y};
         if (j < 2 * H) {  // block-row k0, column pair j of [D|R]
             const float4 v = j < LQ0 ? q0[j] : t0.q[j];
-            a0 = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, a0);
-            a0 = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, a0);
+            a00 = __builtin_elementwise_fma(v2f{v.x, v.y}, xv, a00);
+            a01 = __builtin_elementwise_fma(v2f{v.z, v.w}, xv, a01);
             if (j >= H) {
-                tt0[2 * (j - H)] = fma_t(v.y, o0.y, v.x * o0.x);
-                tt0[2 * (j - H) + 1] = fma_t(v.w, o0.y, v.z * o0.x);
+                const v2f tp = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{o0.y, o0.y}, v2f{v.x, v.y} * v2f{o0.x, o0.x});
+                tt0[2 * (j - H)] = tp.x;
+                tt0[2 * (j - H) + 1] = tp.y;
             }
         }
         if (j >= H) {     // block-row k1, column pair j - H
             const float4 v = K1_FROM_LDS ? q1[j - H] : t1.q[j - H];
-            a1 = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{xv.x, xv.x}, a1);
-            a1 = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{xv.y, xv.y}, a1);
+            a10 = __builtin_elementwise_fma(v2f{v.x, v.y}, xv, a10);
+            a11 = __builtin_elementwise_fma(v2f{v.z, v.w}, xv, a11);
             if (j >= 2 * H) {
-                tt1[2 * (j - 2 * H)] = fma_t(v.y, o1.y, v.x * o1.x);
-                tt1[2 * (j - 2 * H) + 1] = fma_t(v.w, o1.y, v.z * o1.x);
+                const v2f tp = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{o1.y, o1.y}, v2f{v.x, v.y} * v2f{o1.x, o1.x});
+                tt1[2 * (j - 2 * H)] = tp.x;
+                tt1[2 * (j - 2 * H) + 1] = tp.y;
             }
         }
-        asm volatile("" : "+v"(a0), "+v"(a1) : : "memory");
+        asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11) : : "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (j == 2 * H - 1) {
             symres_reduce_scatter14(tt0, lane, u0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    y0[0] = a0.x; y0[1] = a0.y;
-    y1[0] = a1.x; y1[1] = a1.y;
+    y0[0] = a00.x + a00.y; y0[1] = a01.x + a01.y;
+    y1[0] = a10.x + a10.y; y1[1] = a11.x + a11.y;
 }
 
 // Sum tt[c] over the 8 lanes of the aligned group and leave entries 2rp, 2rp+1 in lane rp:
