@@ -231,7 +231,6 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
 // written as asm blocks: hipcc otherwise pairs the adds into v_pk_add_f32 fed by v_mov_b32_dpp copies
 // (3x the instructions).  Each block starts with the two wait states a DPP read of a freshly written
 // VGPR needs; inside a block every instruction touches its own register.
-#define GBDPCG_DPP_ADD(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n"
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2])
 {
 #define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_half_mirror row_mask:0xf bank_mask:0xf\n"
@@ -255,7 +254,6 @@ __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t
     out[0] = b0 ? w2 : w0;
     out[1] = b0 ? w3 : w1;
 }
-#undef GBDPCG_DPP_ADD
 
 // Pull one 128-byte line of the NEXT problem's [D|R] blocks towards the Infinity Cache while this problem
 // iterates: every CU finishes its solve at about the same time, so without this all 256 CUs hit HBM
