@@ -152,23 +152,25 @@ __device__ __forceinline__ void symres_stage_pick(const float *region, uint32_t 
     for (uint32_t i = 0; i < n; ++i) asm volatile("" : "+v"(t.q[i].x), "+v"(t.q[i].y), "+v"(t.q[i].z), "+v"(t.q[i].w));
 }
 
-// Both block-rows of the lane in ONE pass over the operand window [x_k0 ; x_k1 ; x_k1+1] (21 pairs):
-//   pairs  0.. 6 (x_k0)   : D_k0
-//   pairs  7..13 (x_k1)   : R_k0 (+ its transposed share tt0) and D_k1    -> two independent FMA chains
-//   pairs 14..20 (x_k1+1) : R_k1 (+ tt1)
-// x_k1 is read once instead of twice, the first seven pairs are requested before anything else (nothing
-// else is live yet), later pairs AHX steps ahead, LDS-resident tile pieces AHT steps ahead.  tt0 is
-// reduce-scattered between the second and the third phase (u0), tt1 by the caller.
+// Both block-rows of the lane against the operand window [x_k0 ; x_k1 ; x_k1+1] (21 LDS pairs, x_k1 read once
+// for both), in two phases of n/2 steps with six independent packed instructions per step:
+//   phase 1, x_k1 pair j         : R_k0 piece j (+ its transposed share tt0) and D_k1 piece j
+//   phase 2, x_k0 / x_k1+1 pair j: D_k0 piece j, and R_k1 piece j (+ tt1)
+// (a pass in operand order -- D_k0 alone, then the shared middle, then R_k1 alone -- leaves two thin
+// stretches in which a wave has only two dependent FMA chains to issue and waits on their latency: 3.5 %
+// slower).  The x_k1 pairs are requested before anything else, later pairs AHX steps ahead, LDS-resident
+// tile pieces AHT steps ahead (deeper prefetch measured slower).  tt0 is reduce-scattered between the two
+// phases (u0), tt1 by the caller.
 // LQ0 leading pieces of the k0 tile come from LDS (lt0, one float4 per lane and piece, stride THREADS);
 // K1_FROM_LDS: the whole k1 tile is read from LDS (lt1, one float4 per lane and piece, stride 64).
 // The steps are pinned in source order and the accumulators anchored: left to itself hipcc hoists all
 // LDS reads to the top and sinks the accumulator chains below the reduce-scatter, and the operands of
 // every step stay live (with three resident tiles, 168 VGPRs, that spills).
 #ifndef GBDPCG_RS_AHX
-#define GBDPCG_RS_AHX 4
+#define GBDPCG_RS_AHX 3
 #endif
 #ifndef GBDPCG_RS_AHT
-#define GBDPCG_RS_AHT 3
+#define GBDPCG_RS_AHT 2
 #endif
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2]);
 
@@ -177,50 +179,70 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
                                            const float4_alias *lt1, const float2 *xk2, float2 o0, float2 o1, uint32_t lane,
                                            float (&y0)[2], float (&y1)[2], float (&u0)[2], float (&tt1)[NCT])
 {
-    constexpr uint32_t n = NCT, H = n / 2, STEPS = 3 * H, TH = SymResGeom<NCT>::THREADS;
+    constexpr uint32_t n = NCT, H = n / 2, TH = SymResGeom<NCT>::THREADS;
     constexpr uint32_t AHX = GBDPCG_RS_AHX, AHT = GBDPCG_RS_AHT;
     typedef float v2f __attribute__((ext_vector_type(2)));
-    float2 xq[STEPS];  // only a sliding window of it is ever live
+    static_assert(AHX <= H && AHT <= H, "prefetch distances are counted inside one phase");
+    float2 xm[H], xa_[H], xc[H];  // sliding windows: only a few entries of each are ever live
     float4 q0[LQ0 > 0 ? LQ0 : 1], q1[n];
 #pragma unroll
-    for (uint32_t j = 0; j < H; ++j) xq[j] = xk2[j];
+    for (uint32_t j = 0; j < H; ++j) xm[j] = xk2[H + j];
 #pragma unroll
     for (uint32_t i = 0; i < LQ0; ++i) q0[i] = lt0[i * TH];
-    // per block-row and row of the lane: (sum over even columns, sum over odd columns)
+#pragma unroll
+    for (uint32_t i = 0; i < AHT; ++i)
+        if (K1_FROM_LDS) q1[i] = lt1[i * 64];
     v2f a00 = {0.f, 0.f}, a01 = {0.f, 0.f}, a10 = {0.f, 0.f}, a11 = {0.f, 0.f};
     float tt0[NCT];
 #pragma unroll
-    for (uint32_t j = 0; j < STEPS; ++j) {
-        // requests for later steps
-        if (j >= H - AHX && j + AHX < STEPS && j + AHX >= H) xq[j + AHX] = xk2[j + AHX];
-        if (K1_FROM_LDS && j + AHT >= H && j + AHT - H < n) q1[j + AHT - H] = lt1[(j + AHT - H) * 64];
-        const v2f xv = {xq[j].x, xq[j].y};
-        if (j < 2 * H) {  // block-row k0, column pair j of [D|R]
-            const float4 v = j < LQ0 ? q0[j] : t0.q[j];
+    for (uint32_t j = 0; j < H; ++j) {
+        if (K1_FROM_LDS && j + AHT < n) q1[j + AHT] = lt1[(j + AHT) * 64];
+        if (j + AHX >= H && j + AHX - H < H) {  // requests for the first steps of phase 2
+            xa_[j + AHX - H] = xk2[j + AHX - H];
+            xc[j + AHX - H] = xk2[2 * H + j + AHX - H];
+        }
+        const v2f xv = {xm[j].x, xm[j].y};
+        {
+            const float4 v = t0.q[H + j];  // R_k0 (the LDS-resident leading pieces of a k0 tile are D pieces)
             a00 = __builtin_elementwise_fma(v2f{v.x, v.y}, xv, a00);
             a01 = __builtin_elementwise_fma(v2f{v.z, v.w}, xv, a01);
-            if (j >= H) {
-                const v2f tp = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{o0.y, o0.y}, v2f{v.x, v.y} * v2f{o0.x, o0.x});
-                tt0[2 * (j - H)] = tp.x;
-                tt0[2 * (j - H) + 1] = tp.y;
-            }
+            const v2f tp = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{o0.y, o0.y}, v2f{v.x, v.y} * v2f{o0.x, o0.x});
+            tt0[2 * j] = tp.x;
+            tt0[2 * j + 1] = tp.y;
         }
-        if (j >= H) {     // block-row k1, column pair j - H
-            const float4 v = K1_FROM_LDS ? q1[j - H] : t1.q[j - H];
+        {
+            const float4 v = K1_FROM_LDS ? q1[j] : t1.q[j];  // D_k1
             a10 = __builtin_elementwise_fma(v2f{v.x, v.y}, xv, a10);
             a11 = __builtin_elementwise_fma(v2f{v.z, v.w}, xv, a11);
-            if (j >= 2 * H) {
-                const v2f tp = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{o1.y, o1.y}, v2f{v.x, v.y} * v2f{o1.x, o1.x});
-                tt1[2 * (j - 2 * H)] = tp.x;
-                tt1[2 * (j - 2 * H) + 1] = tp.y;
-            }
         }
         asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11) : : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (j == 2 * H - 1) {
-            symres_reduce_scatter14(tt0, lane, u0);
-            __builtin_amdgcn_sched_barrier(0);
+    }
+    symres_reduce_scatter14(tt0, lane, u0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (uint32_t j = 0; j < H; ++j) {
+        if (K1_FROM_LDS && H + j + AHT < n) q1[H + j + AHT] = lt1[(H + j + AHT) * 64];
+        if (j + AHX < H) {
+            xa_[j + AHX] = xk2[j + AHX];
+            xc[j + AHX] = xk2[2 * H + j + AHX];
         }
+        const v2f xd = {xa_[j].x, xa_[j].y}, xr = {xc[j].x, xc[j].y};
+        {
+            const float4 v = j < LQ0 ? q0[j] : t0.q[j];  // D_k0
+            a00 = __builtin_elementwise_fma(v2f{v.x, v.y}, xd, a00);
+            a01 = __builtin_elementwise_fma(v2f{v.z, v.w}, xd, a01);
+        }
+        {
+            const float4 v = K1_FROM_LDS ? q1[H + j] : t1.q[H + j];  // R_k1
+            a10 = __builtin_elementwise_fma(v2f{v.x, v.y}, xr, a10);
+            a11 = __builtin_elementwise_fma(v2f{v.z, v.w}, xr, a11);
+            const v2f tp = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{o1.y, o1.y}, v2f{v.x, v.y} * v2f{o1.x, o1.x});
+            tt1[2 * j] = tp.x;
+            tt1[2 * j + 1] = tp.y;
+        }
+        asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
     y0[0] = a00.x + a00.y; y0[1] = a01.x + a01.y;
     y1[0] = a10.x + a10.y; y1[1] = a11.x + a11.y;
