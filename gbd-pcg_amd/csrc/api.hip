@@ -152,20 +152,28 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
             // AUTO: test L_{k+1} == R_k^T on the device (S, then Pinv and-ed in), then launch BOTH kernels:
             // the symmetric one takes the problems that passed, the general one the rest.  No host
             // round trip, so the whole thing stays asynchronous and graph-capturable.
-            if (batch > h->sym_cap) {
+            // one verdict byte per check workgroup when the pair kernel fits the shape (nothing to initialise),
+            // else one flag per problem
+            const uint32_t vpp = check_pair_chunks<T>(n, N);
+            const bool aligned16 = !((reinterpret_cast<uintptr_t>(d_S) | reinterpret_cast<uintptr_t>(d_Pinv)) % 16);
+            const size_t need_flags = (size_t)batch * (vpp && aligned16 ? vpp : 1);
+            if (need_flags > h->sym_cap) {
                 hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                 if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
                     return GBDPCG_ERR_ALLOC;
-                gbdpcg_status st = ensure_sym_flags(h, batch);
+                gbdpcg_status st = ensure_sym_flags(h, need_flags);
                 if (st != GBDPCG_OK) return st;
             }
             hipError_t cerr = hipSuccess;
-            if (launch_check_symmetric_pair<T>(n, N, batch, d_S, d_Pinv, h->sym_flags, stream, &cerr)) {
+            uint32_t stride = 1;
+            if (vpp && launch_check_symmetric_pair<T>(n, N, batch, d_S, d_Pinv, h->sym_flags, stream, &cerr, &stride)) {
                 HIP_TRY(h, cerr);
             } else {
+                stride = 1;
                 HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_S, h->sym_flags, false, stream));
                 HIP_TRY(h, launch_check_symmetric<T>(h->dev, n, N, batch, d_Pinv, h->sym_flags, true, stream));
             }
+            a.sel_stride = stride;
             a.sel = h->sym_flags;
             a.symmetric = true;
             a.want = 1;
@@ -285,7 +293,8 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
     } else if (h->symmetric == 2) {
-        gbdpcg_status st = ensure_sym_flags(h, batch);
+        const uint32_t vpp = check_pair_chunks<T>(n, N);
+        gbdpcg_status st = ensure_sym_flags(h, (size_t)batch * (vpp ? vpp : 1));
         if (st != GBDPCG_OK) return st;
     }
     hipStream_t cs = nullptr;
@@ -509,6 +518,10 @@ gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, 
 {
     if (!h || (elem_size != 4 && elem_size != 8) || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev.device));
+    // the verdict bytes of the device symmetry check (mode 2) must exist before a capture as well
+    const uint32_t vpp = elem_size == 8 ? check_pair_chunks<double>(n, N) : check_pair_chunks<float>(n, N);
+    gbdpcg_status st = ensure_sym_flags(h, (size_t)batch * (vpp ? vpp : 1));
+    if (st != GBDPCG_OK) return st;
     return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
 }
 

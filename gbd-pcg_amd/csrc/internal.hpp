@@ -15,6 +15,15 @@ struct DeviceInfo {
     size_t lds_per_wg_max = 160 * 1024;
 };
 
+// Does this launch own problem `prob`?  (see PcgArgs::sel)
+template <typename A> __device__ __forceinline__ bool pcg_takes(const A &a, uint32_t prob)
+{
+    if (!a.sel) return true;
+    bool sym = true;
+    for (uint32_t c = 0; c < a.sel_stride; ++c) sym &= a.sel[(size_t)prob * a.sel_stride + c] == 1;
+    return sym == (a.want == 1);
+}
+
 template <typename T> struct SpmvArgs {
     const T *M;
     const T *x;
@@ -42,6 +51,7 @@ template <typename T> struct PcgArgs {
     // every problem.
     const uint8_t *sel = nullptr;
     uint8_t want = 0;
+    uint32_t sel_stride = 1;  // verdict bytes per problem (one per workgroup of the check kernel); the flag is their AND
     // Split path, blocking entry points only: a counter in host-visible memory that a problem bumps when
     // it converges, so that the host can stop enqueueing iteration launches (nullptr: not used).
     uint32_t *host_done = nullptr;
@@ -100,7 +110,9 @@ hipError_t launch_fill_words(uint32_t *p, uint32_t v, size_t count, hipStream_t 
 // S and Pinv in one launch (flags = 1 where both are symmetric); false if the shape does not fit.
 template <typename T>
 bool launch_check_symmetric_pair(uint32_t n, uint32_t N, uint32_t batch, const T *A, const T *B, uint8_t *flags,
-                                 hipStream_t s, hipError_t *err);
+                                 hipStream_t s, hipError_t *err, uint32_t *verdicts_per_problem = nullptr);
+// Verdict bytes per problem the pair kernel writes when asked for per-workgroup verdicts (0: shape not supported).
+template <typename T> uint32_t check_pair_chunks(uint32_t n, uint32_t N);
 // Does launch_pcg_fused have a symmetric-streaming kernel for this shape (and would it be used)?
 template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
 

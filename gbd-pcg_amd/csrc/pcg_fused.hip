@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
-        if (a.sel && (a.sel[prob] == 1) != (a.want == 1)) continue;  // this launch is not the one that owns the problem
+        if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
         const T *S = a.S + prob * mstride;
         const T *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;
         const T *gamma = a.gamma + (size_t)prob * len;

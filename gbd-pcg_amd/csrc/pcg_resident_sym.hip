@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     const size_t mstride = (size_t)3 * n * n * N;
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
-        if (a.sel && (a.sel[prob] == 1) != (a.want == 1)) continue;  // this launch is not the one that owns the problem
+        if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
         const float *S = a.S + prob * mstride;
         const float *P = a.Pinv + prob * mstride;
         const size_t voff = (size_t)prob * len;

@@ -92,7 +92,7 @@ template <typename T>
 __global__ __launch_bounds__(kPairThreads) void check_symmetric_pair_kernel(uint32_t n, uint32_t N, uint32_t ppw,
                                                                             uint32_t chunks, const T *__restrict__ A,
                                                                             const T *__restrict__ B,
-                                                                            uint8_t *__restrict__ flags)
+                                                                            uint8_t *__restrict__ flags, uint32_t per_chunk)
 {
     using V4 = typename NtVec<float, 4>::type;  // 16 bytes, whatever T is
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -132,26 +132,46 @@ __global__ __launch_bounds__(kPairThreads) void check_symmetric_pair_kernel(uint
         bad |= bits_of(ea[ri]) != bits_of(ea[li]);
         if (B) bad |= bits_of(eb[ri]) != bits_of(eb[li]);
     }
-    if (bad) flags[prob] = 0;
+    if (per_chunk) {
+        // one verdict byte per workgroup, written unconditionally: nothing has to be initialised beforehand
+        // (the solve launches AND the bytes of a problem, internal.hpp: pcg_takes)
+        const int any_bad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) flags[(size_t)prob * chunks + chunk] = any_bad ? 0 : 1;
+    } else if (bad) {
+        flags[prob] = 0;
+    }
 }
 
 // Both matrices of a solve in one pass (B may be null).  Returns false when the shape / alignment does
 // not fit the pair kernel; the caller then uses launch_check_symmetric per matrix.
 template <typename T>
+uint32_t check_pair_chunks(uint32_t n, uint32_t N)
+{
+    if (n % 2 || N < 2) return 0;
+    const uint32_t vecs_per_pair = 2 * n * n * sizeof(T) / 16;
+    const uint32_t ppw = kPairVPT * kPairThreads / vecs_per_pair;
+    return ppw ? (N - 1 + ppw - 1) / ppw : 0;
+}
+
+template <typename T>
 bool launch_check_symmetric_pair(uint32_t n, uint32_t N, uint32_t batch, const T *A, const T *B, uint8_t *flags,
-                                 hipStream_t s, hipError_t *err)
+                                 hipStream_t s, hipError_t *err, uint32_t *verdicts_per_problem)
 {
     const uint32_t nn = n * n;
     if (n % 2 || N < 2 || (reinterpret_cast<uintptr_t>(A) % 16) || (B && reinterpret_cast<uintptr_t>(B) % 16)) return false;
     const uint32_t vecs_per_pair = 2 * nn * sizeof(T) / 16;
     const uint32_t ppw = kPairVPT * kPairThreads / vecs_per_pair;
     if (ppw == 0) return false;
-    *err = launch_fill_bytes(flags, 1, batch, s);
-    if (*err != hipSuccess) return true;
     const uint32_t chunks = (N - 1 + ppw - 1) / ppw;
+    if (verdicts_per_problem) {
+        *verdicts_per_problem = chunks;  // flags holds batch * chunks bytes, every one written by the kernel
+    } else {
+        *err = launch_fill_bytes(flags, 1, batch, s);
+        if (*err != hipSuccess) return true;
+    }
     const size_t lds = (size_t)2 * ppw * vecs_per_pair * 16;
     hipLaunchKernelGGL(check_symmetric_pair_kernel<T>, dim3(batch * chunks), dim3(kPairThreads), lds, s, n, N, ppw, chunks,
-                       A, B, flags);
+                       A, B, flags, verdicts_per_problem ? 1u : 0u);
     *err = hipGetLastError();
     return true;
 }
@@ -194,9 +214,11 @@ hipError_t launch_check_symmetric(const DeviceInfo &, uint32_t n, uint32_t N, ui
 }
 
 template bool launch_check_symmetric_pair<float>(uint32_t, uint32_t, uint32_t, const float *, const float *, uint8_t *,
-                                                 hipStream_t, hipError_t *);
+                                                 hipStream_t, hipError_t *, uint32_t *);
 template bool launch_check_symmetric_pair<double>(uint32_t, uint32_t, uint32_t, const double *, const double *, uint8_t *,
-                                                  hipStream_t, hipError_t *);
+                                                  hipStream_t, hipError_t *, uint32_t *);
+template uint32_t check_pair_chunks<float>(uint32_t, uint32_t);
+template uint32_t check_pair_chunks<double>(uint32_t, uint32_t);
 template hipError_t launch_check_symmetric<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const float *, uint8_t *,
                                                   bool, hipStream_t);
 template hipError_t launch_check_symmetric<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const double *,

@@ -117,8 +117,8 @@ gbdpcg_status gbdpcg_check_occupancy(gbdpcg_handle_t h, uint32_t elem_size, uint
                                      uint32_t batch);
 
 /* Bytes of device workspace the SPLIT path needs for this shape (0 for FUSED).  The handle
- * grows its own workspace on demand outside stream capture; call gbdpcg_reserve first when
- * a solve will be captured into a caller-owned graph. */
+ * grows its own workspace (and the verdict bytes of the device symmetry check) on demand outside
+ * stream capture; call gbdpcg_reserve first when a solve will be captured into a caller-owned graph. */
 size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
                               uint32_t batch);
 gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
