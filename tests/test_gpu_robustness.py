@@ -180,3 +180,30 @@ def test_back_to_back_graph_replays_keep_the_symmetric_path(solver):
     graph.close()
     assert int(it.min()) == 10 and int(it.max()) == 10
     assert queued < 1.5 * synced, (queued, synced)
+
+
+def test_solve_inside_a_caller_owned_capture(solver, orc):
+    """gbdpcg_solve_* is capture-safe once gbdpcg_reserve has been called for the shape: a solve captured into a
+    graph the CALLER owns (here torch's) -- default symmetric mode, so the device check, the resident symmetric
+    launch and the general launch are all inside -- replays to the oracle's answer."""
+    n, N, B = 14, 90, 5
+    d = synth.gen_numpy(n, N, seed=404, batch=B, dtype=np.float32)
+    S, g = dev(d["S"]), dev(d["gamma"])
+    P = solver.form_pinv(n, N, B, S, binding.PINV_STAIR)
+    lam = torch.zeros_like(g)
+    iters = torch.zeros(B, dtype=torch.int32, device="cuda")
+    flags = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    solver.reserve(4, n, N, B)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        solver.solve(n, N, B, S, P, g, lam, tol=1e-6, max_iter=40, iters=iters, max_iter_exit=flags)
+    for _ in range(2):
+        lam.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    ob = orc.pcg_batch(n, N, B, d["S"], P.cpu().numpy(), d["gamma"], tol=1e-6, max_iter=40)
+    assert np.array_equal(iters.cpu().numpy().astype(np.int64), ob["iters"].astype(np.int64))
+    lam_h = lam.cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        assert np.linalg.norm(lam_h[b] - ob["lambda_"][b]) / np.linalg.norm(ob["lambda_"][b]) < 1e-6
