@@ -456,8 +456,13 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             if (lane == 0) RED[wave] = ws;                                                                    \
             __syncthreads();                                                                                  \
             const float4 ra = reinterpret_cast<const float4 *>(RED)[0], rb = reinterpret_cast<const float4 *>(RED)[1]; \
-            GBDPCG_SYMRES_FINISH_Y()                                                                          \
+            float2 zz = *reinterpret_cast<const float2 *>(zs + zo0);                                          \
             TOT = ((ra.x + ra.y) + (ra.z + ra.w)) + ((rb.x + rb.y) + (rb.z + rb.w));                          \
+            /* pinned here: left alone, hipcc sinks this LDS read below the division that follows (a second  \
+               round trip on the critical path) */                                                            \
+            asm volatile("" : "+v"(zz.x), "+v"(zz.y));                                                        \
+            y[0][0] += live0 ? zz.x : 0.f;                                                                    \
+            y[0][1] += live0 ? zz.y : 0.f;                                                                    \
         }
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
         GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, p0, true, xb, part)
