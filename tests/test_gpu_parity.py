@@ -481,6 +481,26 @@ def test_symmetric_resident_kernel_iteration_edges(solver, orc, mode, tol, max_i
         assert np.abs(out[key] - ob[key]).max() < 1e-5 * scale, key
 
 
+def test_symmetric_resident_kernel_ill_conditioned(solver, orc):
+    """Generator with a = 0.9 (kappa(S) of several hundred, 55 iterations): on the resident symmetric path the
+    iteration counts stay within one of the fp32 oracle's and the distance to an fp64 solve of the same fp32 data
+    is the oracle's own (iteration counts are order-sensitive on hard systems, so no exact equality here)."""
+    n, N, B = 14, 128, 3
+    d = synth.gen_numpy(n, N, seed=77, batch=B, dtype=np.float64, a=0.9)
+    S32, g32 = d["S"].astype(np.float32), d["gamma"].astype(np.float32)
+    P = solver.form_pinv(n, N, B, dev(S32), binding.PINV_STAIR)
+    Ph = P.cpu().numpy()
+    truth = orc.pcg_batch(n, N, B, S32.astype(np.float64), Ph.astype(np.float64), g32.astype(np.float64), tol=1e-14,
+                          max_iter=500)
+    o32 = orc.pcg_batch(n, N, B, S32, Ph, g32, tol=1e-6, max_iter=300)
+    out = gpu_solve(solver, n, N, B, S32, Ph, g32, tol=1e-6, max_iter=300, path=binding.PATH_FUSED)
+    assert not out["max_iter_exit"].any()
+    assert np.abs(out["iters"].astype(np.int64) - o32["iters"].astype(np.int64)).max() <= 1
+    for b in range(B):
+        e_gpu, e_orc = relerr(out["lambda_"][b], truth["lambda_"][b]), relerr(o32["lambda_"][b], truth["lambda_"][b])
+        assert e_gpu < 1.5 * e_orc + 1e-6
+
+
 def test_symmetric_resident_kernel_unaligned(solver, orc):
     """Matrices that are only 8-byte aligned (a view 2 floats into a buffer) take the resident kernel's
     direct-load form instead of the coalesced 16-byte one; same answers."""
