@@ -68,3 +68,13 @@ def test_example_drivers_print_like_the_reference(exe):
     lam = np.array([float(v) for v in out[2].split()])
     want = np.array([-303.702986086, -46.415939681, -315.176302632, -14.898309418, -298.790861920, 13.503782688])
     assert lam.shape == (6,) and np.linalg.norm(lam - want) / np.linalg.norm(want) < (2e-4 if exe == "pcg_solve" else 1e-5)
+
+
+def test_batched_control_loop_example():
+    """examples/mpc_batch_loop.cpp: the C ABI the way a batched MPC pipeline would use it (Pinv formed on the device,
+    one graph replayed per control step).  The program returns 0 only if the true residual of the solve is small."""
+    exe = os.path.join(EX, "mpc_batch_loop")
+    assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() makes it"
+    out = subprocess.run([exe, "48", "100", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "step 1:" in out.stdout and "||gamma - S lambda||" in out.stdout
