@@ -255,14 +255,19 @@ __device__ __forceinline__ void symres_mv2(const SymResTile<NCT> &t0, const floa
 // VGPR needs; inside a block every instruction touches its own register.
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2])
 {
-#define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_half_mirror row_mask:0xf bank_mask:0xf\n"
-    asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7) D(8) D(9) D(10) D(11) D(12) D(13)
-                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
-                   "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]));
-#undef D
-    const bool hi = (lane & 4u) != 0;
-    float u0 = hi ? t[8] : t[0], u1 = hi ? t[9] : t[1], u2 = hi ? t[10] : t[2], u3 = hi ? t[11] : t[3];
-    float u4 = hi ? t[12] : t[4], u5 = hi ? t[13] : t[5], u6 = hi ? 0.f : t[6], u7 = hi ? 0.f : t[7];
+    // Stage 1 (partner 7-i) with the selection folded into the adds: the lower half of every 8-lane group is
+    // DPP banks 0 and 2 of a row, the upper half banks 1 and 3, so two bank-masked adds into the same register
+    // give each half the entries it keeps (c < 8 below, c >= 8 above) without any v_cndmask.
+    float u0, u1, u2, u3, u4, u5, u6 = 0.f, u7 = 0.f;
+#define LO(u, a) "v_add_f32_dpp %" #u ", %" #a ", %" #a " row_half_mirror row_mask:0xf bank_mask:0x5\n"
+#define HI(u, a) "v_add_f32_dpp %" #u ", %" #a ", %" #a " row_half_mirror row_mask:0xf bank_mask:0xa\n"
+    asm volatile("s_nop 1\n" LO(0, 8) HI(0, 16) LO(1, 9) HI(1, 17) LO(2, 10) HI(2, 18) LO(3, 11) HI(3, 19) LO(4, 12) HI(4, 20)
+                 LO(5, 13) HI(5, 21) LO(6, 14) LO(7, 15)
+                 : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "+v"(u6), "+v"(u7)
+                 : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]),
+                   "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(t[12]), "v"(t[13]));
+#undef LO
+#undef HI
 #define D(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
     asm volatile("s_nop 1\n" D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7)
                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));
