@@ -335,7 +335,15 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     float4_alias *ltw = reinterpret_cast<float4_alias *>(smem + wave * G::GROUPS * G::REGION) + lane;
     const uint32_t zo1 = n + (live1 ? k1 + 1 : 0u) * n + rp * 2;  // where this lane's k1 -> k1+1 products go
     const uint32_t zo0 = n + (live0 ? k0 : 0u) * n + rp * 2;      // ... and where the ones for its k0 rows arrive
+    // the lane's own operand entries inside a mirror; dead lanes read the zero padding in front of x_0 instead, so
+    // nothing downstream needs a select (v_cndmask with an SGPR mask turned out to be the costliest VALU op here)
+    const uint32_t own0 = live0 ? n + row0 : 0u, own1 = live1 ? n + row1 : 0u;
     const size_t mstride = (size_t)3 * n * n * N;
+
+    // zs: only the rows of even block-rows >= 2 are ever written; row 0 (nothing above block-row 0) and the odd
+    // rows (read, harmlessly, by the lanes that own no rows) must hold zeros for the whole launch
+    for (uint32_t i = tid; i < padded; i += G::THREADS) zs[i] = 0.f;
+    __syncthreads();
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
         if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
@@ -403,7 +411,6 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         for (uint32_t i = tid; i < n; i += G::THREADS) {
             xa[i] = 0.f; xa[n + len + i] = 0.f; xa[2 * n + len + i] = 0.f;
             xb[i] = 0.f; xb[n + len + i] = 0.f; xb[2 * n + len + i] = 0.f;
-            zs[n + i] = 0.f;  // block-row 0 has nothing above it; never written afterwards
         }
         __syncthreads();
 
@@ -417,10 +424,8 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 #define GBDPCG_SYMRES_PRODUCT(T0, LQ0, T1, K1LDS, XM, PART)                                                  \
         {                                                                                                     \
             float tt[NCT], u0[2], u1[2];                                                                      \
-            float2 o0 = *reinterpret_cast<const float2 *>(XM + n + row0);                                     \
-            float2 o1 = *reinterpret_cast<const float2 *>(XM + n + row1);                                     \
-            o0.x = live0 ? o0.x : 0.f; o0.y = live0 ? o0.y : 0.f;                                             \
-            o1.x = live1 ? o1.x : 0.f; o1.y = live1 ? o1.y : 0.f;                                             \
+            const float2 o0 = *reinterpret_cast<const float2 *>(XM + own0);                                   \
+            const float2 o1 = *reinterpret_cast<const float2 *>(XM + own1);                                   \
             GBDPCG_SYMRES_MV(T0, LQ0, T1, K1LDS, XM)                                                            \
             symres_reduce_scatter14(tt, lane, u1);                                                            \
             y[1][0] += u0[0];                                                                                 \
@@ -431,14 +436,14 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             PART = fma_t(o0.y, y[0][1], PART);                                                                \
             PART = fma_t(o1.x, y[1][0], PART);                                                                \
             PART = fma_t(o1.y, y[1][1], PART);                                                                \
-            PART = fma_t(live1 ? u1[0] : 0.f, xn.x, PART);                                                    \
-            PART = fma_t(live1 ? u1[1] : 0.f, xn.y, PART);                                                    \
+            PART = fma_t(u1[0], xn.x, PART);  /* dead lanes: u1 == 0 (zero tiles, zero own entries) */         \
+            PART = fma_t(u1[1], xn.y, PART);                                                                  \
         }
 #define GBDPCG_SYMRES_FINISH_Y()                                                                              \
         {                                                                                                     \
             const float2 z = *reinterpret_cast<const float2 *>(zs + zo0);                                     \
-            y[0][0] += live0 ? z.x : 0.f;                                                                     \
-            y[0][1] += live0 ? z.y : 0.f;                                                                     \
+            y[0][0] += z.x;  /* lanes without rows read rows of zs nobody writes: zero since kernel start */  \
+            y[0][1] += z.y;                                                                                   \
         }
         float2 *xa0 = reinterpret_cast<float2 *>(xa + n + row0), *xa1 = reinterpret_cast<float2 *>(xa + n + row1);
         float2 *xb0 = reinterpret_cast<float2 *>(xb + n + row0), *xb1 = reinterpret_cast<float2 *>(xb + n + row1);
@@ -466,8 +471,8 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             /* pinned here: left alone, hipcc sinks this LDS read below the division that follows (a second  \
                round trip on the critical path) */                                                            \
             asm volatile("" : "+v"(zz.x), "+v"(zz.y));                                                        \
-            y[0][0] += live0 ? zz.x : 0.f;                                                                    \
-            y[0][1] += live0 ? zz.y : 0.f;                                                                    \
+            y[0][0] += zz.x;                                                                                  \
+            y[0][1] += zz.y;                                                                                  \
         }
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
         GBDPCG_SYMRES_PRODUCT(p0, G::P0_LDS_QUADS, p0, true, xb, part)
