@@ -159,7 +159,7 @@ __device__ __forceinline__ void symres_stage_pick(const float *region, uint32_t 
 // (a pass in operand order -- D_k0 alone, then the shared middle, then R_k1 alone -- leaves two thin
 // stretches in which a wave has only two dependent FMA chains to issue and waits on their latency: 3.5 %
 // slower).  The x_k1 pairs are requested before anything else, later pairs AHX steps ahead, LDS-resident
-// tile pieces AHT steps ahead (deeper prefetch measured slower).  tt0 is reduce-scattered between the two
+// tile pieces AHT steps ahead (3 and 1: the measured optimum; deeper prefetch is slower).  tt0 is reduce-scattered between the two
 // phases (u0), tt1 by the caller.
 // LQ0 leading pieces of the k0 tile come from LDS (lt0, one float4 per lane and piece, stride THREADS);
 // K1_FROM_LDS: the whole k1 tile is read from LDS (lt1, one float4 per lane and piece, stride 64).
@@ -170,7 +170,7 @@ __device__ __forceinline__ void symres_stage_pick(const float *region, uint32_t 
 #define GBDPCG_RS_AHX 3
 #endif
 #ifndef GBDPCG_RS_AHT
-#define GBDPCG_RS_AHT 2
+#define GBDPCG_RS_AHT 1
 #endif
 __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t lane, float (&out)[2]);
 
