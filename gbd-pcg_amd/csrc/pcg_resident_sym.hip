@@ -282,19 +282,19 @@ __device__ __forceinline__ void symres_reduce_scatter14(float (&t)[14], uint32_t
     out[1] = b0 ? w3 : w1;
 }
 
-// Pull one 128-byte line of the NEXT problem's [D|R] blocks towards the Infinity Cache while this problem
-// iterates: every CU finishes its solve at about the same time, so without this all 256 CUs hit HBM
+// Pull the NEXT problem's [D|R] blocks towards the Infinity Cache, one dword touched per 64 bytes (measured:
+// a 128-byte stride leaves part of the stream in HBM and costs 3 us per batch), while this problem iterates: every CU finishes its solve at about the same time, so without this all 256 CUs hit HBM
 // with their 401 KB tile loads in the same burst.  The load is an LDS-DMA (no VGPR destination, so
 // nothing the compiler allocates can be clobbered when it lands) into a dump area of LDS that
 // is never read; it is hidden from hipcc's waitcnt bookkeeping, so no barrier or LDS read waits for it.
 template <int NCT>
 __device__ __forceinline__ void symres_touch(const float *M, uint32_t N, uint32_t slot, uint32_t lds_dump)
 {
-    // slot -> (block-row k, 128-byte step j inside its [D_k | R_k]); L blocks are never touched
-    constexpr uint32_t row_bytes = 2 * NCT * NCT * 4, steps = (row_bytes + 127) / 128 + 1;
+    // slot -> (block-row k, 64-byte step j inside its [D_k | R_k]); L blocks are never touched
+    constexpr uint32_t row_bytes = 2 * NCT * NCT * 4, steps = (row_bytes + 63) / 64 + 1;
     const uint32_t k = slot / steps, j = slot - k * steps;
     const uint32_t kk = k < N ? k : 0u;
-    uint32_t off = j * 128;
+    uint32_t off = j * 64;
     if (off > row_bytes - 4) off = row_bytes - 4;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(M) + ((size_t)kk * 3 * NCT * NCT + NCT * NCT) * 4 + off;
     unsigned keep;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 
         // prefetch schedule for the next problem of this workgroup: two lines per thread and iteration
         const uint32_t nprob = prob + gridDim.x;
-        constexpr uint32_t pf_steps = (2 * n * n * 4 + 127) / 128 + 1;  // 128-byte steps per [D|R] row (symres_touch)
+        constexpr uint32_t pf_steps = (2 * n * n * 4 + 63) / 64 + 1;  // 64-byte steps per [D|R] row (symres_touch)
         const uint32_t pf_per_matrix = nprob < a.batch ? (N * pf_steps + G::THREADS - 1) / G::THREADS : 0u;
         uint32_t pf = 0;
 #define GBDPCG_SYMRES_PREFETCH()                                                                              \
