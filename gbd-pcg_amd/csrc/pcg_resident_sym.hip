@@ -26,6 +26,13 @@
 #include "bt_sym.hpp"
 #include "internal.hpp"
 
+#ifndef GBDPCG_RS_TILE_NT
+#define GBDPCG_RS_TILE_NT 1
+#endif
+#ifndef GBDPCG_RS_PREFETCH
+#define GBDPCG_RS_PREFETCH 1
+#endif
+
 namespace gbdpcg {
 
 template <int NCT> struct SymResGeom {
@@ -113,8 +120,12 @@ __device__ __forceinline__ void symres_stage_issue(const float *__restrict__ M, 
     for (uint32_t i = 0; i < G::STG_ITERS; ++i) {
         const uint32_t piece = l8 + 8 * i;
         const uint32_t safe = (8 * i + 7 < G::ROW_PIECES || piece < G::ROW_PIECES) ? piece : 0u;  // never past the row
+#if GBDPCG_RS_TILE_NT
         const auto v = __builtin_nontemporal_load(reinterpret_cast<const NtVec<float, 4>::type *>(src + safe));
         st.b[i] = make_float4(v.x, v.y, v.z, v.w);
+#else
+        st.b[i] = src[safe];
+#endif
     }
 }
 // keep_d / keep_r: whether the D / R half may be used at all (dead group, R_{N-1}); zeros are parked otherwise.
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         // prefetch schedule for the next problem of this workgroup: two lines per thread and iteration
         const uint32_t nprob = prob + gridDim.x;
         constexpr uint32_t pf_steps = (2 * n * n * 4 + 63) / 64 + 1;  // 64-byte steps per [D|R] row (symres_touch)
-        const uint32_t pf_per_matrix = nprob < a.batch ? (N * pf_steps + G::THREADS - 1) / G::THREADS : 0u;
+        const uint32_t pf_per_matrix = GBDPCG_RS_PREFETCH && nprob < a.batch ? (N * pf_steps + G::THREADS - 1) / G::THREADS : 0u;
         uint32_t pf = 0;
 #define GBDPCG_SYMRES_PREFETCH()                                                                              \
         if (pf < pf_per_matrix) {                                                                             \
