@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/gbdpcg.h"
 #include "internal.hpp"
@@ -29,6 +30,10 @@ struct gbdpcg_context {
     // split-path workspace, grown on demand outside capture
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // Buffers replaced by a larger one.  Graphs built earlier (gbdpcg_graph_create_solve_*, or a caller's own
+    // capture of gbdpcg_solve_*) hold the OLD pointers in their kernel nodes, so growth never frees: the old
+    // buffer stays valid until the handle goes.  Sizes at least double, which bounds the total at 2x the largest.
+    std::vector<void *> retired;
 };
 
 struct gbdpcg_graph {
@@ -98,43 +103,41 @@ template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint3
     return GBDPCG_PATH_FUSED;
 }
 
-gbdpcg_status ensure_ws(gbdpcg_handle_t h, size_t bytes)
+// Grow *buf to at least `need` bytes (at least doubling); the old buffer is retired, not freed (see
+// gbdpcg_context::retired).  Never called while a stream of this handle is capturing.
+gbdpcg_status grow_buffer(gbdpcg_handle_t h, void **buf, size_t *cap, size_t need)
 {
-    if (bytes <= h->ws_bytes) return GBDPCG_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)cs;
-    if (h->ws) {
-        HIP_TRY(h, hipDeviceSynchronize());
-        HIP_TRY(h, hipFree(h->ws));
-        h->ws = nullptr;
-        h->ws_bytes = 0;
+    if (need <= *cap) return GBDPCG_OK;
+    size_t want = need > 2 * *cap ? need : 2 * *cap;
+    want = (want + 255) / 256 * 256;
+    void *fresh = nullptr;
+    hipError_t e = hipMalloc(&fresh, want);
+    if (e != hipSuccess && want != (need + 255) / 256 * 256) {  // doubling was too much: exactly what is needed
+        want = (need + 255) / 256 * 256;
+        e = hipMalloc(&fresh, want);
     }
-    hipError_t e = hipMalloc(&h->ws, bytes);
     if (e != hipSuccess) {
         h->last_err = e;
         return GBDPCG_ERR_ALLOC;
     }
-    h->ws_bytes = bytes;
+    if (*buf) {
+        try {
+            h->retired.push_back(*buf);
+        } catch (const std::bad_alloc &) {
+            (void)hipFree(fresh);
+            return GBDPCG_ERR_ALLOC;
+        }
+    }
+    *buf = fresh;
+    *cap = want;
     return GBDPCG_OK;
 }
 
+gbdpcg_status ensure_ws(gbdpcg_handle_t h, size_t bytes) { return grow_buffer(h, &h->ws, &h->ws_bytes, bytes); }
+
 gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
 {
-    if (batch <= h->sym_cap) return GBDPCG_OK;
-    if (h->sym_flags) {
-        HIP_TRY(h, hipDeviceSynchronize());
-        HIP_TRY(h, hipFree(h->sym_flags));
-        h->sym_flags = nullptr;
-        h->sym_cap = 0;
-    }
-    const size_t cap = (batch + 255) / 256 * 256;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&h->sym_flags), cap);
-    if (e != hipSuccess) {
-        h->last_err = e;
-        return GBDPCG_ERR_ALLOC;
-    }
-    h->sym_cap = cap;
-    return GBDPCG_OK;
+    return grow_buffer(h, reinterpret_cast<void **>(&h->sym_flags), &h->sym_cap, batch);
 }
 
 template <typename T>
@@ -407,6 +410,7 @@ gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
     (void)hipSetDevice(h->dev.device);
     if (h->ws) (void)hipFree(h->ws);
     if (h->sym_flags) (void)hipFree(h->sym_flags);
+    for (void *old : h->retired) (void)hipFree(old);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->h_iters) (void)hipHostFree(h->h_iters);
     delete h;
@@ -500,7 +504,7 @@ gbdpcg_status gbdpcg_check_occupancy(gbdpcg_handle_t h, uint32_t elem_size, uint
     HIP_TRY(h, hipSetDevice(h->dev.device));
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
     const size_t need = gbdpcg_workspace_bytes(h, elem_size, n, N, batch);
-    return need <= free_b + h->ws_bytes ? GBDPCG_OK : GBDPCG_ERR_TOO_LARGE;
+    return need <= h->ws_bytes || need <= free_b ? GBDPCG_OK : GBDPCG_ERR_TOO_LARGE;  // growth keeps the old buffer
 }
 
 size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)

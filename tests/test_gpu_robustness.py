@@ -207,3 +207,45 @@ def test_solve_inside_a_caller_owned_capture(solver, orc):
     lam_h = lam.cpu().numpy().reshape(B, -1)
     for b in range(B):
         assert np.linalg.norm(lam_h[b] - ob["lambda_"][b]) / np.linalg.norm(ob["lambda_"][b]) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(14, 40, 3, 400, np.float32), (36, 256, 1, 4, np.float64)])
+def test_graph_survives_growth_of_the_handle_buffers(orc, shape):
+    """A graph holds the handle's scratch (the verdict bytes of the device symmetry check; the split path's
+    workspace) in its kernel nodes.  A later, larger solve through the same handle must grow that scratch without
+    freeing what the graph points at: replay the first graph afterwards and compare with the oracle."""
+    n, N, B, B_big, dtype = shape
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    tol = 1e-6 if dtype == np.float32 else 1e-10
+    s = binding.Solver(0)  # a fresh handle: nothing reserved yet
+    try:
+        d = synth.gen_numpy(n, N, seed=515, batch=B, dtype=dtype)
+        S, g = dev(d["S"]), dev(d["gamma"])
+        P = s.form_pinv(n, N, B, S, binding.PINV_STAIR)
+        lam = torch.zeros_like(g)
+        iters = torch.zeros(B, dtype=torch.int32, device="cuda")
+        flags = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        graph = s.graph_solve(n, N, B, S, P, g, lam, None, None, 1e-6, 40, iters, flags)
+        graph.launch()
+        torch.cuda.synchronize()
+        first = lam.clone()
+        # larger batch through the same handle: forces both scratch buffers to grow
+        big = synth.gen_torch(n, N, B_big, "cuda", tdt, seed=99)
+        Pb = s.form_pinv(n, N, B_big, big["S"], binding.PINV_STAIR)
+        lb = torch.zeros_like(big["gamma"])
+        s.solve(n, N, B_big, big["S"], Pb, big["gamma"], lb, tol=1e-6, max_iter=40)
+        torch.cuda.synchronize()
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]  # reuse of any freed block
+        lam.zero_()
+        graph.launch()
+        torch.cuda.synchronize()
+        del junk
+        graph.close()
+        assert torch.equal(lam, first)
+        ob = orc.pcg_batch(n, N, B, d["S"], P.cpu().numpy(), d["gamma"], tol=1e-6, max_iter=40)
+        assert np.array_equal(iters.cpu().numpy().astype(np.int64), ob["iters"].astype(np.int64))
+        lam_h = lam.cpu().numpy().reshape(B, -1)
+        for b in range(B):
+            assert relerr(lam_h[b], ob["lambda_"][b]) < tol
+    finally:
+        s.close()
