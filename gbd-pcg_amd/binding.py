@@ -207,6 +207,35 @@ class Solver:
         self._check(fn(*args, ctypes.byref(g)), "graph_create_solve")
         return Graph(self, g, keep=(S, Pinv, gamma, lam, r, p, iters, max_iter_exit))
 
+    def _form_solve_args(self, n, N, batch, S, Pinv, kind, gamma, lam, r, p, tol, max_iter, iters, mie):
+        suf, a = self.solve_args(n, N, batch, S, Pinv, gamma, lam, r, p, tol, max_iter, iters, mie)
+        # (h, n, N, batch, S, Pinv, | kind, | gamma, lam, r, p, tol, max_iter, iters, mie)
+        return suf, a[:6] + (ctypes.c_int(kind),) + a[6:]
+
+    def form_pinv_solve(self, n, N, batch, S, Pinv, gamma, lam, kind=PINV_STAIR, r=None, p=None, tol=1e-6,
+                        max_iter=25, iters=None, max_iter_exit=None, stream=None):
+        """gbdpcg_form_pinv_solve_*: Pinv (output) formed from S, then the solve, one call.  Returns (iters, flags)."""
+        import torch
+        if iters is None:
+            iters = torch.empty(batch, dtype=torch.int32, device=S.device)
+        if max_iter_exit is None:
+            max_iter_exit = torch.empty(batch, dtype=torch.uint8, device=S.device)
+        suf, args = self._form_solve_args(n, N, batch, S, Pinv, kind, gamma, lam, r, p, tol, max_iter, iters,
+                                          max_iter_exit)
+        fn = getattr(self.lib, f"gbdpcg_form_pinv_solve_{suf}")
+        self._check(fn(*args, self._stream(stream)), "form_pinv_solve")
+        return iters, max_iter_exit
+
+    def graph_form_pinv_solve(self, n, N, batch, S, Pinv, gamma, lam, r, p, tol, max_iter, iters, max_iter_exit,
+                              kind=PINV_STAIR):
+        """Capture Pinv formation + solve into one hipGraph (gbdpcg_graph_create_form_pinv_solve_*)."""
+        suf, args = self._form_solve_args(n, N, batch, S, Pinv, kind, gamma, lam, r, p, tol, max_iter, iters,
+                                          max_iter_exit)
+        g = ctypes.c_void_p()
+        fn = getattr(self.lib, f"gbdpcg_graph_create_form_pinv_solve_{suf}")
+        self._check(fn(*args, ctypes.byref(g)), "graph_create_form_pinv_solve")
+        return Graph(self, g, keep=(S, Pinv, gamma, lam, r, p, iters, max_iter_exit))
+
     def form_pinv(self, n, N, batch, S, kind=PINV_STAIR, Pinv=None, stream=None):
         import torch
         suf, _ = _suffix(S)

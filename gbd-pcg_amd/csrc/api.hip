@@ -143,7 +143,8 @@ gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
 template <typename T>
 gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S, const T *d_Pinv,
                          const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
-                         uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream, bool blocking = false)
+                         uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream, bool blocking = false,
+                         uint32_t given_verdict_stride = 0)
 {
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
@@ -151,7 +152,18 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     HIP_TRY(h, hipSetDevice(h->dev.device));
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED) {
         const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
-        if (has_sym && h->symmetric == 2) {
+        if (has_sym && h->symmetric == 2 && given_verdict_stride) {
+            // the verdict bytes are already in h->sym_flags, put there on this stream by the stair kernel that just
+            // formed Pinv from S (gbdpcg_form_pinv_solve_*): no test launch
+            a.sel_stride = given_verdict_stride;
+            a.sel = h->sym_flags;
+            a.symmetric = true;
+            a.want = 1;
+            HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+            a.symmetric = false;
+            a.want = 0;
+            HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+        } else if (has_sym && h->symmetric == 2) {
             // AUTO: test L_{k+1} == R_k^T on the device (S, then Pinv and-ed in), then launch BOTH kernels:
             // the symmetric one takes the problems that passed, the general one the rest.  No host
             // round trip, so the whole thing stays asynchronous and graph-capturable.
@@ -223,6 +235,45 @@ gbdpcg_status spmv_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batc
     return GBDPCG_OK;
 }
 
+// Verdict bytes a (n, N, batch) solve in symmetric mode 2 may need: the larger of what the test kernel and the
+// one-launch stair kernel write per problem.
+template <typename T> size_t verdict_bytes(uint32_t n, uint32_t N, uint32_t batch)
+{
+    const uint32_t a = check_pair_chunks<T>(n, N), b = pinv_verdict_chunks<T>(n, N, GBDPCG_PINV_STAIR);
+    const uint32_t m = a > b ? a : b;
+    return (size_t)batch * (m ? m : 1);
+}
+
+// Phi^-1 from S, then the solve, on one stream.  When the stair kernel can report, per problem, that S was exactly
+// symmetric (then so is the Pinv it wrote), the solve takes those verdicts instead of launching its own test.
+template <typename T>
+gbdpcg_status form_pinv_solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S, T *d_Pinv,
+                                   gbdpcg_pinv_kind kind, const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol,
+                                   uint32_t max_iter, uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream)
+{
+    if (!h || !d_S || !d_Pinv || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch) || (int)kind < 0 ||
+        (int)kind > 2)
+        return GBDPCG_ERR_INVALID;
+    if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
+    HIP_TRY(h, hipSetDevice(h->dev.device));
+    uint32_t stride = 0;
+    if (h->symmetric == 2 && pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED &&
+        fused_has_symmetric<T>(h->dev, n, N, batch))
+        stride = pinv_verdict_chunks<T>(n, N, (int)kind);
+    if (stride) {
+        const size_t need = verdict_bytes<T>(n, N, batch);
+        if (need > h->sym_cap) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GBDPCG_ERR_ALLOC;
+            gbdpcg_status st = ensure_sym_flags(h, need);
+            if (st != GBDPCG_OK) return st;
+        }
+    }
+    HIP_TRY(h, launch_form_pinv<T>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, stream, stride ? h->sym_flags : nullptr));
+    return solve_impl<T>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit, stream,
+                         false, stride);
+}
+
 template <typename T>
 gbdpcg_status solve_blocking_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, const T *d_S, const T *d_Pinv,
                                   const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
@@ -286,7 +337,8 @@ gbdpcg_status solve_host_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, const T
 template <typename T>
 gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S,
                                 const T *d_Pinv, const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol,
-                                uint32_t max_iter, uint32_t *d_iters, uint8_t *d_exit, gbdpcg_graph_t *out)
+                                uint32_t max_iter, uint32_t *d_iters, uint8_t *d_exit, gbdpcg_graph_t *out,
+                                int form_kind = -1)  // >= 0: the graph also forms Pinv (written through d_Pinv) from S
 {
     if (!h || !out) return GBDPCG_ERR_INVALID;
     *out = nullptr;
@@ -296,8 +348,7 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
     } else if (h->symmetric == 2) {
-        const uint32_t vpp = check_pair_chunks<T>(n, N);
-        gbdpcg_status st = ensure_sym_flags(h, (size_t)batch * (vpp ? vpp : 1));
+        gbdpcg_status st = ensure_sym_flags(h, verdict_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
     }
     hipStream_t cs = nullptr;
@@ -311,8 +362,12 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     gbdpcg_status st = GBDPCG_OK;
     if (e == hipSuccess) {
-        st = solve_impl<T>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit,
-                           cs);
+        if (form_kind >= 0)
+            st = form_pinv_solve_impl<T>(h, n, N, batch, d_S, const_cast<T *>(d_Pinv), (gbdpcg_pinv_kind)form_kind, d_gamma,
+                                         d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit, cs);
+        else
+            st = solve_impl<T>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit,
+                               cs);
         hipError_t e2 = hipStreamEndCapture(cs, &g->graph);
         if (st == GBDPCG_OK && e2 != hipSuccess) st = fail(h, e2);
     } else {
@@ -523,8 +578,7 @@ gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, 
     if (!h || (elem_size != 4 && elem_size != 8) || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev.device));
     // the verdict bytes of the device symmetry check (mode 2) must exist before a capture as well
-    const uint32_t vpp = elem_size == 8 ? check_pair_chunks<double>(n, N) : check_pair_chunks<float>(n, N);
-    gbdpcg_status st = ensure_sym_flags(h, (size_t)batch * (vpp ? vpp : 1));
+    gbdpcg_status st = ensure_sym_flags(h, elem_size == 8 ? verdict_bytes<double>(n, N, batch) : verdict_bytes<float>(n, N, batch));
     if (st != GBDPCG_OK) return st;
     return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
 }
@@ -637,6 +691,44 @@ gbdpcg_status gbdpcg_form_pinv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, ui
     HIP_TRY(h, hipSetDevice(h->dev.device));
     HIP_TRY(h, launch_form_pinv<double>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, (hipStream_t)stream));
     return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_form_pinv_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const float *d_S,
+                                         float *d_Pinv, gbdpcg_pinv_kind kind, const float *d_gamma, float *d_lambda,
+                                         float *d_r, float *d_p, float tol, uint32_t max_iter, uint32_t *d_iters,
+                                         uint8_t *d_max_iter_exit, void *stream)
+{
+    return form_pinv_solve_impl<float>(h, n, N, batch, d_S, d_Pinv, kind, d_gamma, d_lambda, d_r, d_p, tol, max_iter,
+                                       d_iters, d_max_iter_exit, (hipStream_t)stream);
+}
+gbdpcg_status gbdpcg_form_pinv_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const double *d_S,
+                                         double *d_Pinv, gbdpcg_pinv_kind kind, const double *d_gamma, double *d_lambda,
+                                         double *d_r, double *d_p, double tol, uint32_t max_iter, uint32_t *d_iters,
+                                         uint8_t *d_max_iter_exit, void *stream)
+{
+    return form_pinv_solve_impl<double>(h, n, N, batch, d_S, d_Pinv, kind, d_gamma, d_lambda, d_r, d_p, tol, max_iter,
+                                        d_iters, d_max_iter_exit, (hipStream_t)stream);
+}
+
+gbdpcg_status gbdpcg_graph_create_form_pinv_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                                      const float *d_S, float *d_Pinv, gbdpcg_pinv_kind kind,
+                                                      const float *d_gamma, float *d_lambda, float *d_r, float *d_p,
+                                                      float tol, uint32_t max_iter, uint32_t *d_iters,
+                                                      uint8_t *d_max_iter_exit, gbdpcg_graph_t *out)
+{
+    if (!d_Pinv || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;
+    return graph_create_impl<float>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters,
+                                    d_max_iter_exit, out, (int)kind);
+}
+gbdpcg_status gbdpcg_graph_create_form_pinv_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                                      const double *d_S, double *d_Pinv, gbdpcg_pinv_kind kind,
+                                                      const double *d_gamma, double *d_lambda, double *d_r, double *d_p,
+                                                      double tol, uint32_t max_iter, uint32_t *d_iters,
+                                                      uint8_t *d_max_iter_exit, gbdpcg_graph_t *out)
+{
+    if (!d_Pinv || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;
+    return graph_create_impl<double>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters,
+                                     d_max_iter_exit, out, (int)kind);
 }
 
 gbdpcg_status gbdpcg_csr_to_bt_f32(uint32_t n, uint32_t N, const uint32_t *row_ptr, const uint32_t *col_ind,

@@ -117,8 +117,11 @@ template <typename T> uint32_t check_pair_chunks(uint32_t n, uint32_t N);
 template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
 
 // ---- pinv.hip
+// verdicts (optional, only when pinv_verdict_chunks() != 0): pinv_verdict_chunks bytes per problem, 1 = every pair of
+// that chunk was exactly symmetric in S and therefore is in Pinv (pcg_takes ANDs them).
 template <typename T>
 hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S,
-                            T *Pinv, int kind, hipStream_t s);
+                            T *Pinv, int kind, hipStream_t s, uint8_t *verdicts = nullptr);
+template <typename T> uint32_t pinv_verdict_chunks(uint32_t n, uint32_t N, int kind);
 
 }  // namespace gbdpcg

@@ -487,9 +487,12 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
 // in LDS and evaluates the 15 stair pairs between them from there -- the D^-1 blocks are neither re-read from
 // memory nor waited for across a launch boundary.  Consecutive workgroups overlap by one knot (inverted
 // twice, written once).  Same operations, same bits as the two-pass form.
+// verdicts (optional): one byte per workgroup, 1 when every pair of the chunk had L_{k+1} == R_k^T bit for bit
+// in S -- the pairs of Pinv were then written as mirror images, so the same holds for Pinv and a solve that
+// follows needs no symmetry test of its own (gbdpcg_form_pinv_solve_*).  Written unconditionally.
 template <typename T, int NCT>
 __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t N, uint32_t chunks, const T *__restrict__ S,
-                                                                       T *__restrict__ Pinv)
+                                                                       T *__restrict__ Pinv, uint8_t *__restrict__ verdicts)
 {
     constexpr uint32_t n = NCT, nn = n * n, NP = (n + 3) / 4 * 4, H = n / 2, PAIRS = 15;
     static_assert(n <= 16 && n % 2 == 0, "quarter-wave elimination and 2 x 2 tiles");
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
     const uint32_t tr = lane / H, tc = lane - tr * H, r0 = 2 * tr, c0 = 2 * tc;
     const bool tile = lane < H * H;
     constexpr uint32_t EPL = (nn + 63) / 64;
+    bool any_asymmetric = false;
     for (uint32_t j = wave; j < PAIRS && k0 + j + 1 < N; j += 4) {
         const uint32_t k = k0 + j;
         const T *A = inv[j], *C = inv[j + 1];
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
             }
         }
         const bool symmetric = __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
+        any_asymmetric |= !symmetric;
         group_sync<64>();
         for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
             if (pass == 1) {
@@ -623,6 +628,10 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
             group_sync<64>();
         }
     }
+    if (verdicts) {  // uniform branch: every wave reaches the barrier
+        const int bad = __syncthreads_or(any_asymmetric ? 1 : 0);
+        if (threadIdx.x == 0) verdicts[(size_t)prob * chunks + chunk] = bad ? 0 : 1;
+    }
 }
 
 template <typename T, int GT, int EPT_MAX>
@@ -668,10 +677,24 @@ static hipError_t launch_stair_only(const DeviceInfo &dev, uint32_t n, uint32_t 
     return hipGetLastError();
 }
 
+// Workgroups per problem of the one-launch stair kernel when launch_form_pinv will use it for this shape (it is
+// the only form that can report symmetry verdicts), else 0.
+template <typename T> uint32_t pinv_verdict_chunks(uint32_t n, uint32_t N, int kind)
+{
+    static const bool two_pass = getenv("GBDPCG_PINV_TWO_PASS") != nullptr;  // tuning runs only
+    if (kind != 2 || N < 2 || two_pass || n > 16 || n % 2) return 0;
+    bool specialised = false;
+#define GBDPCG_CASE(NN) specialised |= n == NN;
+    GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
+    return specialised ? (N - 1 + 14) / 15 : 0;
+}
+
 template <typename T>
 hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
-                            int kind, hipStream_t s)
+                            int kind, hipStream_t s, uint8_t *verdicts)
 {
+    if (verdicts && pinv_verdict_chunks<T>(n, N, kind) == 0) return hipErrorInvalidValue;  // caller asks first
     // register-resident tableau for the compile-time block sizes with 2n <= 64 lanes
 #define GBDPCG_CASE(NN)                                                                                              \
     if constexpr (2 * NN <= 64) {                                                                                    \
@@ -679,12 +702,11 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
             const uint64_t knots = (uint64_t)N * batch, blocks = (knots + 3) / 4;                                    \
             if (blocks > 0x7fffffffull) return hipErrorInvalidValue;                                                 \
             if constexpr (NN <= 16 && NN % 2 == 0) {                                                                 \
-                static const bool two_pass = getenv("GBDPCG_PINV_TWO_PASS") != nullptr; /* tuning runs only */      \
-                if (kind == 2 && N >= 2 && !two_pass) {                                                              \
-                    const uint32_t chunks = (N - 1 + 14) / 15;                                                       \
+                const uint32_t chunks = pinv_verdict_chunks<T>(n, N, kind);                                          \
+                if (chunks) {                                                                                        \
                     if ((uint64_t)chunks * batch > 0x7fffffffull) return hipErrorInvalidValue;                       \
                     hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN>), dim3(chunks * batch), dim3(kPinvThreads), 0, s, N, \
-                                       chunks, S, Pinv);                                                             \
+                                       chunks, S, Pinv, verdicts);                                                   \
                     return hipGetLastError();                                                                        \
                 }                                                                                                    \
             }                                                                                                        \
@@ -718,8 +740,10 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
 }
 
 template hipError_t launch_form_pinv<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const float *,
-                                            float *, int, hipStream_t);
+                                            float *, int, hipStream_t, uint8_t *);
 template hipError_t launch_form_pinv<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const double *,
-                                             double *, int, hipStream_t);
+                                             double *, int, hipStream_t, uint8_t *);
+template uint32_t pinv_verdict_chunks<float>(uint32_t, uint32_t, int);
+template uint32_t pinv_verdict_chunks<double>(uint32_t, uint32_t, int);
 
 }  // namespace gbdpcg

@@ -2,9 +2,11 @@
 // Schur systems per control step does with this library instead of one solvePCG<T> call per problem
 // (/root/reference/include/interface.cuh:92-144 allocates, launches, copies back and frees per call):
 //
-//   once      : buffers, a handle, one executable graph of the solve for those buffers
-//   per step  : (the caller rewrites S and gamma in place), Phi^-1 = symmetric stair from S on the device,
-//               replay the graph, read lambda / iteration counts when they are needed
+//   once      : buffers, a handle, one executable graph of { Phi^-1 = symmetric stair from S ; solve } for those buffers
+//               (gbdpcg_graph_create_form_pinv_solve_f32: the stair kernel's symmetry verdicts feed the solve, which
+//               then needs no test launch of its own)
+//   per step  : (the caller rewrites S and gamma in place), replay the graph, read lambda / iteration counts when
+//               they are needed
 //
 // Builds synthetic symmetric positive definite block-tridiagonal systems on the host (S = G W G^T with a
 // block-bidiagonal G, the structure of an MPC Schur complement), runs a few steps and prints per-step times
@@ -123,15 +125,15 @@ int main(int argc, char **argv)
     GK(gbdpcg_create(&h, 0));
     hipStream_t stream;
     CK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    gbdpcg_graph_t graph;  // default symmetric mode: the device tests L_{k+1} == R_k^T, then takes the resident path
-    GK(gbdpcg_graph_create_solve_f32(h, n, N, batch, dS, dP, dg, dl, nullptr, nullptr, 1e-6f, 50, d_iters, d_flags, &graph));
+    gbdpcg_graph_t graph;  // default symmetric mode: problems whose S has L_{k+1} == R_k^T take the CU-resident path
+    GK(gbdpcg_graph_create_form_pinv_solve_f32(h, n, N, batch, dS, dP, GBDPCG_PINV_STAIR, dg, dl, nullptr, nullptr, 1e-6f, 50,
+                                               d_iters, d_flags, &graph));
 
     std::vector<uint32_t> iters(batch);
     for (int step = 0; step < steps; ++step) {
         // (an MPC pipeline would rewrite dS / dg here from the new linearisation)
         const auto t0 = std::chrono::steady_clock::now();
         CK(hipMemsetAsync(dl, 0, vsz * batch * 4, stream));  // cold start; a warm start keeps the previous lambda
-        GK(gbdpcg_form_pinv_f32(h, n, N, batch, dS, dP, GBDPCG_PINV_STAIR, stream));
         GK(gbdpcg_graph_launch(graph, stream));
         CK(hipStreamSynchronize(stream));
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();

@@ -221,6 +221,36 @@ gbdpcg_status gbdpcg_form_pinv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, ui
                                    const double *d_S, double *d_Pinv, gbdpcg_pinv_kind kind,
                                    void *stream);
 
+/* gbdpcg_form_pinv_* followed by gbdpcg_solve_* on the same stream, as one call: what an SQP step does with a
+ * freshly formed S (the host overload of the reference stops short of it, interface.cuh:33-34).  d_Pinv is an
+ * OUTPUT here and stays valid afterwards.  In symmetric mode 2, for the shapes the one-launch stair kernel covers
+ * (even stateSize <= 16), that kernel already compares L_{k+1} with R_k^T of S pair by pair -- it writes the pair
+ * of Pinv as mirror images when they match -- so its per-problem verdict replaces the solve's own test launch
+ * (74 us of a 0.30 ms converged solve of 1024 problems, n=14, N=128).  Same results as the two calls.
+ * The graph form captures both steps for fixed buffers: replay it after rewriting S and gamma in place. */
+gbdpcg_status gbdpcg_form_pinv_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                         const float *d_S, float *d_Pinv, gbdpcg_pinv_kind kind,
+                                         const float *d_gamma, float *d_lambda, float *d_r, float *d_p,
+                                         float tol, uint32_t max_iter, uint32_t *d_iters,
+                                         uint8_t *d_max_iter_exit, void *stream);
+gbdpcg_status gbdpcg_form_pinv_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch,
+                                         const double *d_S, double *d_Pinv, gbdpcg_pinv_kind kind,
+                                         const double *d_gamma, double *d_lambda, double *d_r, double *d_p,
+                                         double tol, uint32_t max_iter, uint32_t *d_iters,
+                                         uint8_t *d_max_iter_exit, void *stream);
+gbdpcg_status gbdpcg_graph_create_form_pinv_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N,
+                                                      uint32_t batch, const float *d_S, float *d_Pinv,
+                                                      gbdpcg_pinv_kind kind, const float *d_gamma,
+                                                      float *d_lambda, float *d_r, float *d_p, float tol,
+                                                      uint32_t max_iter, uint32_t *d_iters,
+                                                      uint8_t *d_max_iter_exit, gbdpcg_graph_t *out);
+gbdpcg_status gbdpcg_graph_create_form_pinv_solve_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N,
+                                                      uint32_t batch, const double *d_S, double *d_Pinv,
+                                                      gbdpcg_pinv_kind kind, const double *d_gamma,
+                                                      double *d_lambda, double *d_r, double *d_p,
+                                                      double tol, uint32_t max_iter, uint32_t *d_iters,
+                                                      uint8_t *d_max_iter_exit, gbdpcg_graph_t *out);
+
 /* CSR ingestion (f3): repacks a host CSR matrix (csr_t<T>, include/types.cuh:7-15) whose
  * sparsity lies inside the block-tridiagonal pattern into the [L|D|R] layout (host arrays).
  * Entries outside the pattern give GBDPCG_ERR_INVALID.  Implements what the stub overload

@@ -249,3 +249,107 @@ def test_graph_survives_growth_of_the_handle_buffers(orc, shape):
             assert relerr(lam_h[b], ob["lambda_"][b]) < tol
     finally:
         s.close()
+
+
+def _two_calls(solver, n, N, B, S, g, kind, tol, max_iter):
+    P = solver.form_pinv(n, N, B, S, kind)
+    lam = torch.zeros_like(g)
+    it, fl = solver.solve(n, N, B, S, P, g, lam, tol=tol, max_iter=max_iter)
+    torch.cuda.synchronize()
+    return P, lam, it, fl
+
+
+@pytest.mark.parametrize("shape", [(14, 128, 7, np.float32), (14, 31, 3, np.float32), (14, 16, 2, np.float32),
+                                   (12, 50, 4, np.float32), (6, 40, 3, np.float64), (36, 20, 2, np.float64),
+                                   (5, 9, 2, np.float32), (14, 1, 2, np.float32)])
+@pytest.mark.parametrize("kind", [binding.PINV_STAIR, binding.PINV_BLOCK_JACOBI, binding.PINV_IDENTITY])
+def test_form_pinv_solve_equals_the_two_calls(solver, shape, kind):
+    """gbdpcg_form_pinv_solve_* = gbdpcg_form_pinv_* then gbdpcg_solve_*, bit for bit: the stair kernel's symmetry
+    verdicts (where it reports them) select the same kernels as the solve's own test would.  Shapes with and
+    without the one-launch stair kernel, with and without a symmetric solve kernel, N = 1."""
+    n, N, B, dtype = shape
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    d = synth.gen_torch(n, N, B, "cuda", tdt, seed=2024)
+    S, g = d["S"], d["gamma"]
+    P_ref, lam_ref, it_ref, fl_ref = _two_calls(solver, n, N, B, S, g, kind, 1e-6, 30)
+    P = torch.full_like(S, float("nan"))
+    lam = torch.zeros_like(g)
+    it, fl = solver.form_pinv_solve(n, N, B, S, P, g, lam, kind=kind, tol=1e-6, max_iter=30)
+    torch.cuda.synchronize()
+    assert torch.equal(P, P_ref)
+    assert torch.equal(it, it_ref) and torch.equal(fl, fl_ref)
+    assert torch.equal(lam, lam_ref)
+
+
+def test_form_pinv_solve_with_some_asymmetric_problems(solver, orc):
+    """Problems whose S has one L_{k+1} != R_k^T must be solved by the general kernel (their Pinv pair is formed from
+    both sides); the others by the resident symmetric one; all must match the oracle run on the same S and Pinv."""
+    n, N, B = 14, 100, 6
+    d = synth.gen_numpy(n, N, seed=31337, batch=B, dtype=np.float32)
+    S_h = d["S"].reshape(B, N, 3, n, n).copy()
+    S_h[1, 40, 0, 3, 5] *= 1.0 + 2.0 ** -20   # L_40 of problem 1: last-bits perturbation
+    S_h[4, N - 1, 0, 0, 0] += 1e-3            # L_{N-1} of problem 4
+    S = dev(S_h.reshape(-1))
+    g = dev(d["gamma"])
+    P = torch.empty_like(S)
+    lam = torch.zeros_like(g)
+    it, fl = solver.form_pinv_solve(n, N, B, S, P, g, lam, tol=1e-6, max_iter=60)
+    torch.cuda.synchronize()
+    flags = solver.check_symmetric(n, N, B, P).cpu().numpy()
+    assert list(flags) == [1, 0, 1, 1, 0, 1]   # Pinv is exactly symmetric exactly where S was
+    P_ref, lam_ref, it_ref, _ = _two_calls(solver, n, N, B, S, g, binding.PINV_STAIR, 1e-6, 60)
+    assert torch.equal(P, P_ref) and torch.equal(lam, lam_ref) and torch.equal(it, it_ref)
+    ob = orc.pcg_batch(n, N, B, S_h.reshape(-1), P.cpu().numpy(), d["gamma"], tol=1e-6, max_iter=60)
+    # a last-bits asymmetry leaves the operator (numerically) what it was; the iteration counts agree with the oracle's
+    assert np.array_equal(it.cpu().numpy().astype(np.int64), ob["iters"].astype(np.int64))
+    lam_h = lam.cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        assert relerr(lam_h[b], ob["lambda_"][b]) < 2e-6
+
+
+def test_form_pinv_solve_graph_replays_and_skips_the_test_launch(solver):
+    """The captured form + solve replays to the same answer after S is rewritten in place, and costs less than the
+    captured solve alone plus a separate Pinv formation (no symmetry-test launch: 70 us of ~0.5 ms here)."""
+    n, N, B = 14, 128, 1024
+    d = synth.gen_torch(n, N, B, "cuda", torch.float32, seed=5)
+    S, g = d["S"], d["gamma"]
+    P = torch.empty_like(S)
+    lam = torch.zeros_like(g)
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    both = solver.graph_form_pinv_solve(n, N, B, S, P, g, lam, None, None, 1e-6, 40, it, fl)
+    both.launch()
+    torch.cuda.synchronize()
+    P_ref, lam_ref, it_ref, _ = _two_calls(solver, n, N, B, S, g, binding.PINV_STAIR, 1e-6, 40)
+    assert torch.equal(P, P_ref) and torch.equal(lam, lam_ref) and torch.equal(it.to(it_ref.dtype), it_ref)
+    # new S in the same buffers
+    d2 = synth.gen_torch(n, N, B, "cuda", torch.float32, seed=6)
+    S.copy_(d2["S"]); g.copy_(d2["gamma"]); lam.zero_()
+    both.launch()
+    torch.cuda.synchronize()
+    P_ref, lam_ref, it_ref, _ = _two_calls(solver, n, N, B, S, g, binding.PINV_STAIR, 1e-6, 40)
+    assert torch.equal(P, P_ref) and torch.equal(lam, lam_ref) and torch.equal(it.to(it_ref.dtype), it_ref)
+
+    solve_only = solver.graph_solve(n, N, B, S, P, g, lam, None, None, 1e-6, 40, it, fl)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0.record()
+        for _ in range(20):
+            fn()
+        t1.record()
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1) / 20
+
+    def fused():
+        lam.zero_(); both.launch()
+
+    def separate():
+        lam.zero_(); solver.form_pinv(n, N, B, S, binding.PINV_STAIR, Pinv=P); solve_only.launch()
+
+    t_fused, t_sep = timed(fused), timed(separate)
+    both.close(); solve_only.close()
+    assert t_fused < t_sep - 0.03, (t_fused, t_sep)   # ms
