@@ -29,6 +29,8 @@ SYMBOLS = [
     "gbdpcg_solve_blocking_f32", "gbdpcg_solve_blocking_f64", "gbdpcg_solve_host_f32",
     "gbdpcg_solve_host_f64", "gbdpcg_graph_create_solve_f32", "gbdpcg_graph_create_solve_f64",
     "gbdpcg_graph_launch", "gbdpcg_graph_destroy", "gbdpcg_form_pinv_f32", "gbdpcg_form_pinv_f64",
+    "gbdpcg_form_pinv_solve_f32", "gbdpcg_form_pinv_solve_f64",
+    "gbdpcg_graph_create_form_pinv_solve_f32", "gbdpcg_graph_create_form_pinv_solve_f64",
     "gbdpcg_csr_to_bt_f32", "gbdpcg_csr_to_bt_f64", "gbdpcg_version",
 ]
 
