@@ -73,7 +73,9 @@ def main():
                 def step():
                     lam.zero_()
                     graph.launch()
+                it.fill_(-1)  # a replay that solves nothing leaves these behind (it must not inherit an earlier run's counts)
                 med, best = timed(step, args.reps)
+                assert int(it.min()) >= 1 and bool(torch.isfinite(lam).all()), "the timed replays did not solve anything"
                 done = it.float().mean().item()
                 rec = dict(config=name, n=n, N=N, batch=B, dtype=str(dt).replace("torch.", ""), path=pname, run=tag,
                            ms_median=med, ms_best=best, iters_mean=done,
