@@ -342,6 +342,59 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_quad_kernel(uint32_t N
     }
 }
 
+// 32 < n <= 64 (BASELINE config 4: n = 36, fp64): ONE knot per wavefront, lane c < n owns column c, the same
+// in-place elimination as pinv_diag_quad_kernel (the [D | I] tableau kernels need 2n <= 64 lanes, and the
+// LDS form that used to take these sizes spends a workgroup barrier pair per pivot step: 107 us for the 256
+// knots of config 4 against a few us here).  The pivot column is broadcast with v_readlane (n scalars per
+// step, no LDS, no barrier); the finished inverse is staged in LDS for the mirrored, dense write-out.
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_diag_wide_kernel(uint32_t N, uint64_t knots, const T *__restrict__ S,
+                                                                     T *__restrict__ Pinv, int kind)
+{
+    constexpr uint32_t n = NCT, nn = n * n;
+    static_assert(n > 32 && n <= 64, "one column per lane");
+    __shared__ __attribute__((aligned(16))) T stage_all[4][nn];
+    const uint32_t wave = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const uint64_t knot = (uint64_t)blockIdx.x * 4 + wave;
+    const bool alive = knot < knots;  // wave-uniform; dead waves still run the (cheap, branch-free) loop
+    T *stage = stage_all[wave];
+    const size_t blk = (size_t)(alive ? knot : 0) * 3 * nn;
+    const T *D = S + blk + nn;
+    const bool owner = l < n;
+
+    T col[n];
+#pragma unroll
+    for (uint32_t r = 0; r < n; ++r) col[r] = (kind == 0 || !alive || !owner) ? (r == l ? T(1) : T(0)) : D[(owner ? l : 0u) * n + r];
+    if (kind != 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) {  // fully unrolled: every register index is static
+            T cj[n];                        // column j, broadcast from lane j into scalars
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) cj[r] = lane_bcast(col[r], (int)j);
+            const T piv = T(1) / cj[j];
+            const bool is_j = l == j;
+            const T pr = is_j ? piv : col[j] * piv;  // scaled pivot-row entry of this lane's column
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r) col[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+        }
+    }
+    if (owner) {
+#pragma unroll
+        for (uint32_t r = 0; r < n; ++r) stage[l * n + r] = col[r];
+    }
+    group_sync<64>();
+    if (!alive) return;
+    T *o = Pinv + (size_t)knot * 3 * nn;
+    const uint32_t kk = (uint32_t)(knot % N);
+    for (uint32_t i = l; i < nn; i += 64) {
+        const uint32_t c = i / n, r = i - c * n;
+        o[nn + i] = r <= c ? stage[c * n + r] : stage[r * n + c];  // mirror the upper triangle: exactly symmetric
+        // the stair pass overwrites every off-diagonal slot except the two never-read corner blocks
+        if (kind != 2 || kk == 0) o[i] = T(0);
+        if (kind != 2 || kk == N - 1) o[2 * nn + i] = T(0);
+    }
+}
+
 // Stair off-diagonal slots for compile-time n: one wavefront per knot PAIR (k, k+1), every inner product
 // reads BOTH operands as contiguous pairs from LDS.  The wave of knot k produces the right slot of k,
 // R'_k = -D_k^-1 R_k D_{k+1}^-1, and the left slot of k+1, L'_{k+1} = -D_{k+1}^-1 L_{k+1} D_k^-1, evaluated as
@@ -634,6 +687,92 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
     }
 }
 
+// Stair slots for 32 < n <= 64 (even n; BASELINE config 4): one WORKGROUP per knot pair (k, k+1).  The same
+// operation sequence as the wave-per-pair kernels above -- W = D_k^-1 R_k with 2 x 2 register tiles, X = W D_{k+1}^-1,
+// R'_k = -X, and L'_{k+1} = -X^T written as the mirror image when the workgroup finds L_{k+1} == R_k^T in S (else a
+// second pass on L_{k+1}^T) -- with the (n/2)^2 tiles dealt over 256 threads and the factors staged in LDS.  The
+// runtime-n kernel this replaces evaluates every pair twice (once from each side), with scalar inner loops.
+template <typename T, int NCT>
+__global__ __launch_bounds__(kPinvThreads) void pinv_stair_wide_kernel(uint32_t N, const T *__restrict__ S, T *__restrict__ Pinv)
+{
+    constexpr uint32_t n = NCT, nn = n * n, H = n / 2, TILES = H * H;
+    static_assert(n > 32 && n <= 64 && n % 2 == 0 && 4 * nn * sizeof(T) <= 64 * 1024, "four n x n factors in static LDS");
+    using P2 = typename VecOf<T, 2>::type;
+    __shared__ __attribute__((aligned(16))) T A[nn], B[nn], C[nn], Wt[nn];
+    const uint32_t pairs_per_problem = N - 1;
+    const uint32_t prob = blockIdx.x / pairs_per_problem, k = blockIdx.x - prob * pairs_per_problem;
+    const size_t blk = ((size_t)prob * N + k) * 3 * nn, nb = blk + (size_t)3 * nn;
+    constexpr uint32_t EPL = (nn + kPinvThreads - 1) / kPinvThreads;
+    T lt[EPL];
+    bool differs = false;
+#pragma unroll
+    for (uint32_t q = 0; q < EPL; ++q) {
+        const uint32_t i = threadIdx.x + kPinvThreads * q;
+        if (i < nn) {
+            const uint32_t c = i / n, r = i - c * n;
+            const T rk = S[blk + 2 * (size_t)nn + i];   // R_k(r,c)
+            lt[q] = S[nb + (size_t)r * n + c];          // L_{k+1}(c,r)
+            differs |= pinv_bits(rk) != pinv_bits(lt[q]);
+            B[i] = rk;
+            A[i] = Pinv[blk + nn + i];                  // D_k^-1 (mirrored by the diagonal pass: exactly symmetric)
+            C[i] = Pinv[nb + nn + i];                   // D_{k+1}^-1
+        }
+    }
+    const bool symmetric = __syncthreads_or(differs ? 1 : 0) == 0;  // also the barrier after the staging stores
+    for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
+        if (pass == 1) {
+#pragma unroll
+            for (uint32_t q = 0; q < EPL; ++q) {
+                const uint32_t i = threadIdx.x + kPinvThreads * q;
+                if (i < nn) B[i] = lt[q];
+            }
+            __syncthreads();
+        }
+        for (uint32_t t = threadIdx.x; t < TILES; t += kPinvThreads) {
+            const uint32_t tr = t / H, tc = t - tr * H, r0 = 2 * tr, c0 = 2 * tc;
+            const P2 *a0 = reinterpret_cast<const P2 *>(A + r0 * n), *a1 = reinterpret_cast<const P2 *>(A + (r0 + 1) * n);
+            const P2 *b0 = reinterpret_cast<const P2 *>(B + c0 * n), *b1 = reinterpret_cast<const P2 *>(B + (c0 + 1) * n);
+            T w00 = T(0), w01 = T(0), w10 = T(0), w11 = T(0);
+#pragma unroll
+            for (uint32_t q = 0; q < H; ++q) {
+                const P2 x0 = a0[q], x1 = a1[q], y0 = b0[q], y1 = b1[q];
+                w00 = fma_t(x0.x, y0.x, w00); w00 = fma_t(x0.y, y0.y, w00);
+                w01 = fma_t(x0.x, y1.x, w01); w01 = fma_t(x0.y, y1.y, w01);
+                w10 = fma_t(x1.x, y0.x, w10); w10 = fma_t(x1.y, y0.y, w10);
+                w11 = fma_t(x1.x, y1.x, w11); w11 = fma_t(x1.y, y1.y, w11);
+            }
+            Wt[r0 * n + c0] = w00; Wt[r0 * n + c0 + 1] = w01;
+            Wt[(r0 + 1) * n + c0] = w10; Wt[(r0 + 1) * n + c0 + 1] = w11;
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < TILES; t += kPinvThreads) {
+            const uint32_t tr = t / H, tc = t - tr * H, r0 = 2 * tr, c0 = 2 * tc;
+            const P2 *a0 = reinterpret_cast<const P2 *>(Wt + r0 * n), *a1 = reinterpret_cast<const P2 *>(Wt + (r0 + 1) * n);
+            const P2 *b0 = reinterpret_cast<const P2 *>(C + c0 * n), *b1 = reinterpret_cast<const P2 *>(C + (c0 + 1) * n);
+            T x00 = T(0), x01 = T(0), x10 = T(0), x11 = T(0);
+#pragma unroll
+            for (uint32_t q = 0; q < H; ++q) {
+                const P2 u0 = a0[q], u1 = a1[q], y0 = b0[q], y1 = b1[q];
+                x00 = fma_t(u0.x, y0.x, x00); x00 = fma_t(u0.y, y0.y, x00);
+                x01 = fma_t(u0.x, y1.x, x01); x01 = fma_t(u0.y, y1.y, x01);
+                x10 = fma_t(u1.x, y0.x, x10); x10 = fma_t(u1.y, y0.y, x10);
+                x11 = fma_t(u1.x, y1.x, x11); x11 = fma_t(u1.y, y1.y, x11);
+            }
+            if (pass == 0) {
+                T *Rp = Pinv + blk + 2 * (size_t)nn;
+                Rp[c0 * n + r0] = -x00; Rp[c0 * n + r0 + 1] = -x10;
+                Rp[(c0 + 1) * n + r0] = -x01; Rp[(c0 + 1) * n + r0 + 1] = -x11;
+            }
+            if (pass == 1 || symmetric) {
+                T *Lp = Pinv + nb;
+                Lp[r0 * n + c0] = -x00; Lp[r0 * n + c0 + 1] = -x01;
+                Lp[(r0 + 1) * n + c0] = -x10; Lp[(r0 + 1) * n + c0 + 1] = -x11;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, int GT, int EPT_MAX>
 static hipError_t launch_form_pinv_g(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
                                      int kind, hipStream_t s)
@@ -727,6 +866,28 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
             hipLaunchKernelGGL((pinv_stair_reg_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, S, \
                                Pinv);                                                                                \
             return hipGetLastError();                                                                                \
+        }                                                                                                            \
+    }
+    GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
+    // compile-time block sizes with one column per lane (32 < n <= 64): in-place elimination, one knot per wave;
+    // the stair slots then come from the runtime-n LDS kernel
+#define GBDPCG_CASE(NN)                                                                                              \
+    if constexpr (NN > 32 && NN <= 64) {                                                                             \
+        static const bool no_wide = getenv("GBDPCG_PINV_NO_WIDE") != nullptr; /* tuning runs only */                 \
+        if (n == NN && !no_wide) {                                                                                   \
+            const uint64_t knots = (uint64_t)N * batch, blocks = (knots + 3) / 4;                                    \
+            if (blocks > 0x7fffffffull) return hipErrorInvalidValue;                                                 \
+            hipLaunchKernelGGL((pinv_diag_wide_kernel<T, NN>), dim3((uint32_t)blocks), dim3(kPinvThreads), 0, s, N, knots, S, \
+                               Pinv, kind);                                                                          \
+            if (kind != 2 || N < 2) return hipGetLastError();                                                        \
+            if constexpr (NN % 2 == 0 && 4 * NN * NN * sizeof(T) <= 64 * 1024) {                                     \
+                if ((uint64_t)(N - 1) * batch > 0x7fffffffull) return hipErrorInvalidValue;                          \
+                hipLaunchKernelGGL((pinv_stair_wide_kernel<T, NN>), dim3((N - 1) * batch), dim3(kPinvThreads), 0, s, N, S, Pinv); \
+                return hipGetLastError();                                                                            \
+            } else {                                                                                                 \
+                return launch_stair_only<T, 256>(dev, n, N, batch, S, Pinv, s);                                     \
+            }                                                                                                        \
         }                                                                                                            \
     }
     GBDPCG_SPECIALIZED_N(GBDPCG_CASE)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from gbd_pcg_amd import binding, synth
 solver = binding.Solver(0)
-for (n, N, B, dt) in [(14, 128, 1024, torch.float32), (14, 64, 1, torch.float32), (36, 256, 16, torch.float64), (14, 128, 1024, torch.float64)]:
+for (n, N, B, dt) in [(14, 128, 1024, torch.float32), (14, 64, 1, torch.float32), (36, 256, 1, torch.float64), (36, 256, 16, torch.float64), (36, 64, 256, torch.float32), (14, 128, 1024, torch.float64)]:
     g = synth.gen_torch(n, N, B, "cuda", dt, seed=1)
     P = torch.empty_like(g["S"])
     for kind, nm in ((binding.PINV_BLOCK_JACOBI, "jacobi"), (binding.PINV_STAIR, "stair")):

@@ -297,9 +297,10 @@ def test_graph_replay(solver, orc, path):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kind", ["stair", "jacobi", "identity"])
-def test_form_pinv(solver, dtype, kind):
-    """f1: Pinv built on the device from S equals the host construction."""
-    n, N, B = 14, 9, 3
+@pytest.mark.parametrize("n", [14, 36])
+def test_form_pinv(solver, dtype, kind, n):
+    """f1: Pinv built on the device from S equals the host construction (n = 36: one column per lane, in place)."""
+    N, B = 9, 3
     d = synth.gen_numpy(n, N, seed=41, batch=B, dtype=dtype, pinv=kind)
     code = {"stair": binding.PINV_STAIR, "jacobi": binding.PINV_BLOCK_JACOBI, "identity": binding.PINV_IDENTITY}[kind]
     P = solver.form_pinv(n, N, B, dev(d["S"]), code)
@@ -315,7 +316,8 @@ def test_form_pinv(solver, dtype, kind):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n,N,B", [(14, 2, 2), (14, 15, 1), (14, 16, 3), (14, 17, 2), (14, 31, 1), (14, 128, 2),
-                                   (8, 20, 2), (12, 33, 1), (16, 47, 2), (6, 5, 2), (13, 18, 1), (36, 4, 1)])
+                                   (8, 20, 2), (12, 33, 1), (16, 47, 2), (6, 5, 2), (13, 18, 1), (36, 4, 1), (36, 1, 2),
+                                   (36, 2, 1), (36, 21, 3)])
 def test_form_pinv_shapes(solver, dtype, n, N, B):
     """The stair across the kernel families (fused 16-knot workgroups with their chunk seams at 15 / 16 / 17 knots,
     register Gauss-Jordan, LDS forms) against the host construction; exact symmetry wherever S is symmetric."""
@@ -332,11 +334,12 @@ def test_form_pinv_shapes(solver, dtype, n, N, B):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_form_pinv_general_S(solver, dtype):
+@pytest.mark.parametrize("n", [14, 36])
+def test_form_pinv_general_S(solver, dtype, n):
     """The stair of a NON-symmetric S: the device evaluates the left slot of a knot from L_{k+1} itself whenever
     it is not the mirror image of R_k (the mirror shortcut is for symmetric storage only).  One problem keeps
     symmetric storage, the others get perturbed L blocks."""
-    n, N, B = 14, 9, 3
+    N, B = 9, 3
     d = synth.gen_numpy(n, N, seed=43, batch=B, dtype=np.float64)
     L, D, R = (np.array(x) for x in synth.unpack_bt(n, N, d["S"]))
     L[1, 4] *= 1.25
