@@ -95,12 +95,19 @@ template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint3
     if (h->forced == GBDPCG_PATH_FUSED) return fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT;
     if (h->forced == GBDPCG_PATH_SPLIT) return GBDPCG_PATH_SPLIT;
     if (!fits) return GBDPCG_PATH_SPLIT;
-    // A workgroup streams its problem's matrices at roughly one CU's share of bandwidth; with fewer
-    // problems than ~1/4 of the CUs and a matrix big enough that streaming dominates the launch
-    // boundaries of the split path, spreading one problem over many CUs wins.
-    const uint64_t mat_bytes = (uint64_t)6 * n * n * N * sizeof(T);
-    if (batch * 4 < (uint32_t)h->dev.num_cus && mat_bytes > (1u << 20)) return GBDPCG_PATH_SPLIT;
-    return GBDPCG_PATH_FUSED;
+    // Shapes whose matrices stay on the CU for the whole solve: fused, whatever the batch.  (Symmetric mode 2
+    // decides per problem on the device; the path is chosen for the problems that pass.)
+    if (resident_shape<T>(n, N)) return GBDPCG_PATH_FUSED;
+    if (h->symmetric != 0 && resident_sym_shape<T>(n, N)) return GBDPCG_PATH_FUSED;
+    if (batch >= (uint32_t)h->dev.num_cus) return GBDPCG_PATH_FUSED;  // every CU has a problem of its own to stream
+    // Streaming, fewer problems than CUs.  FUSED: one workgroup per problem pulls both matrices through ONE CU's
+    // share of the fabric every iteration (43 GB/s measured on the general kernel: 13.9 us per iteration for the
+    // 602 KB of n=14, N=128 fp32, at any batch below the CU count).  SPLIT: the whole chip streams, at the price of
+    // two dependent launches per iteration (measured on the same shape: 7.5 us at batch 1, 7.8 at 8, 11.8 at 32,
+    // 13.9 at 64 = 7.4 us + batch x bytes at ~6 TB/s).
+    const double bytes = 6.0 * n * n * N * sizeof(T);
+    const double t_fused = bytes / 43e9, t_split = 7.4e-6 + batch * bytes / 6e12;
+    return t_split < t_fused ? GBDPCG_PATH_SPLIT : GBDPCG_PATH_FUSED;
 }
 
 // Grow *buf to at least `need` bytes (at least doubling); the old buffer is retired, not freed (see

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("shape", nargs="*", type=int, default=[14, 128, 1024])
     ap.add_argument("--mode", type=int, default=1)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 fused, 2 split")
     args = ap.parse_args()
     n, N, B = args.shape
     solver = binding.Solver(0)
@@ -28,6 +29,7 @@ def main():
     it = torch.zeros(B, dtype=torch.int32, device="cuda")
     fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
     solver.set_symmetric(args.mode)
+    solver.set_path(args.path)
     xs, ys = [], []
     for iters in (5, 10, 20, 40, 80):
         graph = solver.graph_solve(n, N, B, S, P, gamma, lam, None, None, 0.0, iters, it, fl)
