@@ -635,3 +635,57 @@ def test_full_config3_batch_against_oracle(solver, orc, mode):
     num = np.linalg.norm(out["lambda_"].astype(np.float64) - ob["lambda_"], axis=1)
     den = np.linalg.norm(ob["lambda_"].astype(np.float64), axis=1)
     assert (num / den).max() < F32_TOL
+
+
+# ------------------------------------------------------------------------------------- randomized dispatch sweep
+def _sweep_cases(count=48, seed=20261004):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(count):
+        n = int(rng.choice([1, 2, 3, 5, 6, 7, 8, 12, 13, 14, 14, 14, 16, 18, 24, 25, 36, 40]))
+        N = int(rng.choice([1, 2, 3, 9, 31, 64, 72, 73, 100, 128, 129, 200]))
+        if n * n * N > 400000:
+            N = max(1, 400000 // (n * n))
+        B = int(rng.choice([1, 2, 3, 5, 9]))
+        dtype = [np.float32, np.float64][int(rng.integers(2))]
+        pinv = ["stair", "jacobi", None][int(rng.integers(3))]
+        mode = int(rng.choice([0, 1, 2, 2]))
+        fixed = bool(rng.integers(2))
+        cases.append((i, n, N, B, dtype, pinv, mode, fixed))
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: f"{c[0]}-n{c[1]}-N{c[2]}-B{c[3]}-{np.dtype(c[4]).name}-{c[5]}-m{c[6]}-{'fix' if c[7] else 'tol'}")
+def test_randomized_dispatch_sweep(solver, orc, case):
+    """Seeded random walk over block size, horizon, batch, precision, preconditioner kind (formed ON THE DEVICE, so
+    the stair is exactly symmetric and every symmetric mode is legal), symmetric mode and exit rule, path AUTO:
+    whichever kernel family the dispatch lands on must reproduce the oracle run on the same S and the same Pinv."""
+    _, n, N, B, dtype, pinv, mode, fixed = case
+    d = synth.gen_numpy(n, N, seed=7000 + case[0], batch=B, dtype=dtype)
+    S, g = d["S"], d["gamma"]
+    dS = dev(S)
+    P_h = None
+    if pinv is not None:
+        kind = binding.PINV_STAIR if pinv == "stair" else binding.PINV_BLOCK_JACOBI
+        P_h = solver.form_pinv(n, N, B, dS, kind).cpu().numpy()
+    tol, max_iter = (0.0, 6) if fixed else (1e-6, 200)
+    solver.set_symmetric(mode)
+    try:
+        out = gpu_solve(solver, n, N, B, S, P_h, g, tol=tol, max_iter=max_iter)
+    finally:
+        solver.set_symmetric(2)
+    ob = orc.pcg_batch(n, N, B, S, P_h, g, tol=tol, max_iter=max_iter)
+    bound = F64_TOL if dtype == np.float64 else (F32_TOL if pinv is not None else 4 * F32_TOL)
+    assert np.array_equal(out["max_iter_exit"], ob["max_iter_exit"].astype(bool))
+    # without a preconditioner the fp32 runs take 25-30 iterations and the exit test can land one iteration apart
+    slack = 0 if (dtype == np.float64 or fixed) else 1
+    assert np.abs(out["iters"] - ob["iters"].astype(np.int64)).max() <= slack
+    for b in range(B):
+        if not np.isfinite(ob["lambda_"][b]).all():
+            # fixed iteration count past an exact solve (N = 1 with an exact preconditioner): 0 / 0 in pcg.cuh:169
+            assert not np.isfinite(out["lambda_"][b]).all()
+        elif out["iters"][b] == ob["iters"][b]:
+            assert relerr(out["lambda_"][b], ob["lambda_"][b]) < bound, (b, out["iters"][b])
+        else:
+            A = orc.dense_from_bt(n, N, S[b])
+            assert relerr(out["lambda_"][b], np.linalg.solve(A, g[b].astype(np.float64))) < 1e-4
