@@ -655,6 +655,15 @@ def _sweep_cases(count=48, seed=20261004):
         mode = int(rng.choice([0, 1, 2, 2]))
         fixed = bool(rng.integers(2)) and N > 2  # iterating past the exact solve of a tiny system is 0 / 0 or not by rounding luck
         cases.append((i, n, N, B, dtype, pinv, mode, fixed))
+    # batches beyond the CU count: persistent workgroups, several rounds of the resident kernels, the symmetric
+    # streaming kernels (which are only taken from 256 problems on)
+    for j in range(max(8, count // 6)):
+        n = int(rng.choice([6, 8, 12, 14, 14, 14, 16]))
+        N = int(rng.choice([5, 20, 64, 73, 100, 128]))
+        B = int(rng.integers(256, 700))
+        dtype = [np.float32, np.float64][int(rng.integers(2))]
+        pinv = ["stair", "jacobi"][int(rng.integers(2))]
+        cases.append((count + j, n, N, B, dtype, pinv, int(rng.choice([0, 1, 2, 2])), bool(rng.integers(2))))
     return cases
 
 
@@ -664,8 +673,11 @@ def test_randomized_dispatch_sweep(solver, orc, case):
     the stair is exactly symmetric and every symmetric mode is legal), symmetric mode and exit rule, path AUTO:
     whichever kernel family the dispatch lands on must reproduce the oracle run on the same S and the same Pinv."""
     _, n, N, B, dtype, pinv, mode, fixed = case
-    d = synth.gen_numpy(n, N, seed=7000 + case[0], batch=B, dtype=dtype)
-    S, g = d["S"], d["gamma"]
+    base = min(B, 6)  # large batches repeat six generated systems with rescaled right-hand sides
+    d = synth.gen_numpy(n, N, seed=7000 + case[0], batch=base, dtype=dtype)
+    idx = np.arange(B) % base
+    S = np.ascontiguousarray(d["S"][idx])
+    g = (d["gamma"][idx] * (1.0 + 0.01 * (np.arange(B) // base))[:, None]).astype(dtype)
     dS = dev(S)
     P_h = None
     if pinv is not None:
