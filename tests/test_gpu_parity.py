@@ -708,3 +708,55 @@ def test_randomized_dispatch_sweep(solver, orc, case):
             assert e_gpu < max(2 * e_orc + 10 * bound, 2e-3), (b, e_gpu, e_orc)  # exit rule: |r.r| < 1e-6, kappa < 30
         else:
             assert relerr(out["lambda_"][b], ob["lambda_"][b]) < bound, (b, out["iters"][b])
+
+
+def _aux_cases(count=36, seed=424242):
+    if os.environ.get("GBDPCG_SWEEP"):
+        count, seed = (int(x) for x in os.environ["GBDPCG_SWEEP"].split(","))
+        seed += 1000
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(rng.choice([1, 2, 3, 4, 6, 7, 8, 12, 13, 14, 16, 18, 24, 25, 36, 40]))
+        N = int(rng.choice([1, 2, 3, 14, 15, 16, 17, 30, 31, 46, 64]))
+        B = int(rng.choice([1, 2, 3, 7, 40]))
+        if n * n * N * B > 600000:
+            B = max(1, 600000 // (n * n * N))
+        out.append((i, n, N, B, [np.float32, np.float64][int(rng.integers(2))], bool(rng.integers(2))))
+    return out
+
+
+@pytest.mark.parametrize("case", _aux_cases(), ids=lambda c: f"{c[0]}-n{c[1]}-N{c[2]}-B{c[3]}-{np.dtype(c[4]).name}-{'asym' if c[5] else 'sym'}")
+def test_randomized_pinv_spmv_check(solver, orc, case):
+    """The operators either side of the solve over random shapes: stair formation (symmetric S: mirrored, exactly
+    symmetric output; perturbed S: both slots evaluated) against the host construction in fp64, the symmetry test's
+    per-problem verdicts, and the block-tridiagonal product against the dense one."""
+    i, n, N, B, dtype, asym = case
+    d = synth.gen_numpy(n, N, seed=9000 + i, batch=B, dtype=np.float64)
+    L, D, R = (np.array(x) for x in synth.unpack_bt(n, N, d["S"]))
+    touched = np.zeros(B, bool)
+    if asym and N > 1:
+        rng = np.random.default_rng(i)
+        for b in range(B):
+            if rng.integers(2):
+                k = int(rng.integers(1, N))
+                L[b, k, int(rng.integers(n)), int(rng.integers(n))] *= 1.0 + 2.0 ** -12
+                touched[b] = True
+    S = synth.pack_bt(L, D, R).astype(dtype)
+    dS = dev(S)
+    assert solver.check_symmetric(n, N, B, dS).cpu().numpy().astype(bool).tolist() == (~touched).tolist()
+    P = solver.form_pinv(n, N, B, dS, binding.PINV_STAIR)
+    torch.cuda.synchronize()
+    assert solver.check_symmetric(n, N, B, P).cpu().numpy().astype(bool).tolist() == (~touched).tolist()
+    Lq, Dq, Rq = (np.array(x, dtype=np.float64) for x in synth.unpack_bt(n, N, S))
+    want = synth.pack_bt(*synth.stair_pinv_blocks(Lq, Dq, Rq)).reshape(B, N, 3, n * n).copy()
+    got = P.cpu().numpy().astype(np.float64).reshape(B, N, 3, n * n).copy()
+    for arr in (got, want):
+        arr[:, 0, 0] = 0
+        arr[:, -1, 2] = 0
+    assert relerr(got, want) < (1e-11 if dtype == np.float64 else 3e-5)
+    x = np.stack([synth.normals(77 + b, i, n * N) for b in range(B)]).astype(dtype)
+    y = solver.spmv(n, N, B, dS, dev(x)).cpu().numpy()
+    for b in range(min(B, 4)):
+        A = orc.dense_from_bt(n, N, S[b])
+        assert relerr(y[b], A @ x[b].astype(np.float64)) < (1e-13 if dtype == np.float64 else F32_TOL)
