@@ -747,7 +747,10 @@ def test_randomized_pinv_spmv_check(solver, orc, case):
     assert solver.check_symmetric(n, N, B, dS).cpu().numpy().astype(bool).tolist() == (~touched).tolist()
     P = solver.form_pinv(n, N, B, dS, binding.PINV_STAIR)
     torch.cuda.synchronize()
-    assert solver.check_symmetric(n, N, B, P).cpu().numpy().astype(bool).tolist() == (~touched).tolist()
+    # symmetric S => exactly symmetric Pinv; the converse can fail by rounding (a last-bits change of a tiny element
+    # of S may vanish in the products), so nothing is asserted about the verdict of a perturbed problem's Pinv
+    p_sym = solver.check_symmetric(n, N, B, P).cpu().numpy().astype(bool)
+    assert p_sym[~touched].all()
     Lq, Dq, Rq = (np.array(x, dtype=np.float64) for x in synth.unpack_bt(n, N, S))
     want = synth.pack_bt(*synth.stair_pinv_blocks(Lq, Dq, Rq)).reshape(B, N, 3, n * n).copy()
     got = P.cpu().numpy().astype(np.float64).reshape(B, N, 3, n * n).copy()
