@@ -2,27 +2,38 @@
 """bench.py -- headline benchmark of the MI355X-native block-tridiagonal PCG.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+N > 1 without WORLD_SIZE in the environment: this process is only a LAUNCHER -- it starts N fresh child
+ranks (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before making any GPU call, waits for
+them and prints rank 0's JSON line.  Under torch.distributed.run (WORLD_SIZE set) it is one rank; WORLD_SIZE
+must then equal --gpus.
 
 Workload (BASELINE.json configs[2], the one the north-star target is quoted on): stateSize n = 14,
-knotPoints N = 128, fp32, batch = 1024 independent problems PER GPU (configs[4] is this shape
-sharded over 8 GPUs: weak scaling, no data-path collective), synthetic Schur systems from
-gbd_pcg_amd.synth with the symmetric-stair preconditioner.
+knotPoints N = 128, fp32, 1024 independent problems PER GPU (configs[4] is this shape at 8 GPUs: weak
+scaling, no data-path collective).  The job's batch is problems 0 .. 1024*N-1 of SURVEY.md section 8d's
+Gen(14, 128, 1234 + i, 0.5); rank g owns the contiguous slice sharding.shard_range gives it and builds it
+on its own GPU.  Phi^-1 = symmetric stair formed on the device from S.
 
-A "step" = one batched PCG solve with a fixed iteration count (exit_tol = 0, max_iter = 25: the
-test |eta| < 0 never holds, /root/reference/include/pcg.cuh:195), lambda reset to 0 first, replayed
-from a hipGraph.  value = problem-iterations per second over the whole job.
+A "step" = one batched PCG solve with a fixed iteration count (exit_tol = 0, max_iter = 25: the test
+|eta| < 0 never holds, /root/reference/include/pcg.cuh:195), lambda reset to 0 first, replayed from a
+hipGraph.  value = problem-iterations per second over the whole job (all ranks' units / max elapsed).
 
 Printed JSON line (rank 0) also carries
-  roofline     : the dominant kernel (pcg_resident_sym_kernel), algorithmic bytes / measured kernel time
-                 (HIP events on the launch stream) against the 8 TB/s HBM peak
-  spmv         : the standalone block-tridiagonal SpMV kernel, same accounting (the >= 70 % target)
+  roofline     : the dominant kernel.  pcg_resident_sym_kernel keeps [D|R] of S and Phi^-1 on the CU for the
+                 whole solve, so its bound is fp32 vector issue, not HBM: achieved = flop/s against the
+                 157.3 TFLOP/s fp32 peak (frac <= 1), with the HBM share of the bytes it really moves and the
+                 section-8d algorithmic-bytes figure as a labelled "equivalent stream rate"
+  spmv         : the standalone block-tridiagonal SpMV (the kernel the >= 70 % HBM target is quoted on), timed
+                 over 4 rotating matrices (1.23 GB > the 256 MiB Infinity Cache): an HBM statement
+  configs      : driver-timed numbers for the other single-GPU BASELINE configs (C2, C4, C5's batch on one GPU)
   cpu_baseline : the CPU oracle (oracle/pcg_oracle.c, a port -- the reference has no CPU path)
-                 timed on this host's cores on a bounded sample of the same workload
+                 timed on this host's cores on a bounded sample of the same workload (N = 1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,28 +43,53 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip table)
 HBM_COPY_CEIL_GBPS = 6290.0  # measured float4-copy ceiling, same table
 HBM_COLD_READ_GBPS = 6185.0  # best pure-read kernel (non-temporal loads) on Infinity-Cache-cold data (profiles/r01_bw_probe_cold.txt)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # same table: peak FP32 (vector) = the dense fp32 MFMA peak
+
+N_STATE, N_KNOTS, BATCH_PER_GPU, MAX_ITER = 14, 128, 1024, 25
+BASE_SEED = 1234
+
+
+def profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
-    FETCH_SIZE / WRITE_SIZE runs of this same benchmark, gfx950 x2 read correction calibrated on
-    known-size reads).  None when no profile matches the kernel."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        for name, rec in prof["kernels"].items():
+    """HBM-side bytes per launch from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
+    same benchmark, gfx950 x2 read correction calibrated on known-size reads).  None when no profile matches."""
+    for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        prof = profile_json(f)
+        if not prof:
+            continue
+        for name, rec in prof.get("kernels", {}).items():
             if name.startswith(kernel_prefix):
                 return rec["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
     return None
 
-N_STATE, N_KNOTS, BATCH_PER_GPU, MAX_ITER = 14, 128, 1024, 25
+
+def pmc_valu(kernel_prefix):
+    """VALU-issue utilisation of a kernel from the committed SQ-counter pass (profiles/r02_pmc_sq.json, written by
+    gbd-pcg_amd/tools/pmc_sq_json.py): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES per SIMD, LDS bank-conflict share."""
+    prof = profile_json("r02_pmc_sq.json")
+    if not prof:
+        return None
+    for name, rec in prof.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return rec
+    return None
+
+
+def pcg_flops_per_launch(n, N, batch, iters):
+    """2 flops per stored element of the touched blocks, two products per iteration and two in the prologue
+    (S lambda, Pinv r): (2 iters + 2) * 2 (3N-2) n^2 per problem (SURVEY.md section 8d flop count)."""
+    return batch * (2 * iters + 2) * 2 * (3 * N - 2) * n * n
 
 
 def pcg_bytes_per_launch(n, N, batch, iters, s):
-    """Algorithmic HBM bytes of one fused solve: S and Pinv streamed once per iteration
-    (2 (3N-2) n^2 s) + the prologue's one pass over each + vectors
-    (gamma, lambda in; lambda, r, p out)."""
+    """Algorithmic HBM bytes of one solve by SURVEY.md section 8d: S and Pinv streamed once per iteration
+    (2 (3N-2) n^2 s) + the prologue's one pass over each + vectors (gamma, lambda in; lambda, r, p out)."""
     mat = (3 * N - 2) * n * n * s
     return batch * ((2 * iters + 2) * mat + 5 * n * N * s)
 
@@ -82,7 +118,7 @@ def cpu_baseline(n, N, iters, budget_s=12.0):
     from oracle import oracle as orc
     cores = host_cores()
     probe = max(4 * cores, 32)
-    d = synth.gen_numpy(n, N, seed=1234, batch=probe, dtype=np.float32)
+    d = synth.gen_numpy(n, N, seed=BASE_SEED, batch=probe, dtype=np.float32)
     t0 = time.perf_counter()
     orc.pcg_batch(n, N, probe, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=iters, nthreads=cores)
     t_probe = time.perf_counter() - t0
@@ -92,25 +128,94 @@ def cpu_baseline(n, N, iters, budget_s=12.0):
         orc.pcg_batch(n, N, probe, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=iters, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": probe * reps * iters / dt, "unit": "iter/s", "cores": cores, "kind": "port",
-            "sample": f"{probe} problems x {reps} repeats x {iters} iterations, n={n} N={N} fp32, "
+            "sample": f"problems 0..{probe - 1} of the workload x {reps} repeats x {iters} iterations, n={n} N={N} fp32, "
                       f"OpenMP over problems, {dt:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a torch.distributed environment
+# ---------------------------------------------------------------------------------------------------------
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks):
+    """Start n_ranks fresh child processes of this script, one per GPU, and relay rank 0's output.  The parent
+    makes no GPU call (it never imports torch): every rank initialises its own device in its own process."""
+    import tempfile
+    port = free_port()
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for rank in range(n_ranks):
+            env = dict(os.environ)
+            env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(n_ranks),
+                        "LOCAL_WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if rank == 0 else subprocess.DEVNULL))
+        # wait for all ranks; a rank that dies takes the job down (the others would sit in the rendezvous or a barrier)
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.returncode not in (None, 0) for p in procs):
+                failed = True
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()              # exactly the children started above, by PID
+            time.sleep(0.05)
+        codes = [p.returncode for p in procs]
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
+    if failed or any(codes):
+        sys.stderr.write(f"bench.py launcher: rank exit codes {codes}\n")
+        sys.exit(1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------
+
+def run_dry(args, world, rank):
+    """Host logic of the N > 1 path with no GPU (CPU tests, gloo): rendezvous, sharding, aggregation, the
+    JSON line's bookkeeping.  Solves nothing and reports no metric value."""
+    import torch
+    import torch.distributed as dist
+    from gbd_pcg_amd import sharding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    total = BATCH_PER_GPU * world
+    lo, hi = sharding.shard_range(total, rank, world)
+    spans = [None] * world
+    if world > 1:
+        dist.all_gather_object(spans, (lo, hi, os.getpid()))
+        dist.barrier()
+    else:
+        spans = [(lo, hi, os.getpid())]
+    elapsed, units = sharding.aggregate(1.0 + rank, float((hi - lo) * MAX_ITER * args.steps), device="cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "PCG iterations/sec and GB/s on block-tridiag SpMV, stateSize×knotPoints",
+                          "value": None, "dry_run": True, "n_gpus": dist.get_world_size() if world > 1 else 1,
+                          "steps": args.steps, "warmup": args.warmup, "shards": [list(s[:2]) for s in spans],
+                          "pids": [s[2] for s in spans], "seeds": f"{BASE_SEED} + problem index",
+                          "max_elapsed": elapsed, "total_units": units}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2]
+
+
+def run_rank(args, world, rank, local_rank):
     import torch
     import torch.distributed as dist
     from gbd_pcg_amd import binding, sharding, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     # GBDPCG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box (every rank on cuda:0,
     # aggregation on CPU tensors); the real multi-GPU run uses RCCL ("nccl") with one rank per GPU
@@ -124,21 +229,29 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        world = dist.get_world_size()   # the ranks the collective library actually sees
     agg_device = "cuda" if backend == "nccl" else "cpu"
+    dev = torch.device("cuda", local_rank)
 
-    n, N, B, iters = N_STATE, N_KNOTS, BATCH_PER_GPU, MAX_ITER
+    n, N, iters = N_STATE, N_KNOTS, MAX_ITER
+    total_batch = BATCH_PER_GPU * world
+    lo, hi = sharding.shard_range(total_batch, rank, world)   # rank g owns problems [g B/G, (g+1) B/G)
+    B = hi - lo
     solver = binding.Solver(local_rank)
-    g = synth.gen_torch(n, N, B, "cuda", torch.float32, seed=1234 + 100003 * rank)
+    g = synth.gen_torch_seeded(n, N, lo, hi, dev, torch.float32, seed=BASE_SEED)
     S, gamma = g["S"], g["gamma"]
+    del g
     # Phi^-1 = symmetric stair, formed on the device from S (gbdpcg_form_pinv: exactly symmetric storage)
     P = solver.form_pinv(n, N, B, S, binding.PINV_STAIR)
-    del g
     lam = torch.zeros_like(gamma)
     r, p = torch.empty_like(gamma), torch.empty_like(gamma)
-    it_out = torch.zeros(B, dtype=torch.int32, device="cuda")
-    fl_out = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    it_out = torch.zeros(B, dtype=torch.int32, device=dev)
+    fl_out = torch.zeros(B, dtype=torch.uint8, device=dev)
     graph = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, 0.0, iters, it_out, fl_out)
     stream = torch.cuda.current_stream()
+
+    def new_events(k):
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
 
     def step(ev=None):
         lam.zero_()
@@ -156,8 +269,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
+    events = new_events(args.steps)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -168,80 +280,51 @@ def main():
     elapsed, total_units = sharding.aggregate(elapsed, float(B * iters * args.steps), device=agg_device)
     assert int(it_out.min()) == iters and int(it_out.max()) == iters
     assert torch.isfinite(lam).all()
+    step_ms = median([a.elapsed_time(b) for a, b in events])   # check kernel + both PCG launches of one replay
 
-    step_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps   # check kernels + both PCG launches
-    pcg_bytes = pcg_bytes_per_launch(n, N, B, iters, 4)
-
-    # standalone SpMV over two distinct 308 MB matrices (S, Pinv) so the 256 MiB Infinity Cache
-    # cannot hold the stream between launches
-    x = torch.randn_like(gamma)
-    y = torch.empty_like(gamma)
-    for _ in range(4):
-        solver.spmv(n, N, B, S, x, y)
-        solver.spmv(n, N, B, P, x, y)
-    # 20 launches issued back to back, each bracketed by its own event pair on the launch stream: the
-    # host runs ahead of the 60 us kernels, so a pair times one kernel (what rocprofv3 reports per
-    # dispatch), not the host launch path; three rounds, mean of the middle round's launches
-    SP_LAUNCHES = 20
-    rounds = []
-    for _ in range(3):
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SP_LAUNCHES)]
+    def time_graph(gr, reps, warm=5, reset=None):
+        """Median (and minimum) per-replay HIP-event time of a solve graph on the launch stream."""
+        reset = lam if reset is None else reset
+        for _ in range(warm):
+            reset.zero_()
+            gr.launch(stream)
+        evs = new_events(reps)
         torch.cuda.synchronize()
-        for k, (e0, e1) in enumerate(evs):
+        for e0, e1 in evs:
+            reset.zero_()
             e0.record(stream)
-            solver.spmv(n, N, B, S if k % 2 == 0 else P, x, y)
+            gr.launch(stream)
             e1.record(stream)
         torch.cuda.synchronize()
-        rounds.append(sum(e0.elapsed_time(e1) for e0, e1 in evs[2:]) / (SP_LAUNCHES - 2))
-    sp_ms = sorted(rounds)[1]
-    sp_gbps = spmv_bytes_per_launch(n, N, B, 4) / (sp_ms * 1e-3) / 1e9
-    # the same product with gbdpcg_set_symmetric(1): only [D|R] is read (a device check would cost as
-    # much as the product, so the standalone SpMV uses the symmetric kernel only on the caller's word)
-    solver.set_symmetric(1)
-    rounds = []
-    for _ in range(3):
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SP_LAUNCHES)]
-        torch.cuda.synchronize()
-        for k, (e0, e1) in enumerate(evs):
-            e0.record(stream)
-            solver.spmv(n, N, B, S if k % 2 == 0 else P, x, y)
-            e1.record(stream)
-        torch.cuda.synchronize()
-        rounds.append(sum(e0.elapsed_time(e1) for e0, e1 in evs[2:]) / (SP_LAUNCHES - 2))
-    solver.set_symmetric(2)
-    sps_ms = sorted(rounds)[1]
-    sps_gbps = spmv_bytes_per_launch(n, N, B, 4) / (sps_ms * 1e-3) / 1e9
+        ts = [e0.elapsed_time(e1) for e0, e1 in evs]
+        return median(ts), min(ts)
 
     def time_mode(mode, reps):
-        """Per-replay HIP-event time of the solve graph built under gbdpcg_set_symmetric(mode)."""
         solver.set_symmetric(mode)
         gr = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, 0.0, iters, it_out, fl_out)
         solver.set_symmetric(2)
-        for _ in range(3):
-            lam.zero_()
-            gr.launch(stream)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        torch.cuda.synchronize()
-        for e0, e1 in evs:
-            lam.zero_()
-            e0.record(stream)
-            gr.launch(stream)
-            e1.record(stream)
-        torch.cuda.synchronize()
+        med, best = time_graph(gr, reps)
         assert torch.isfinite(lam).all() and int(it_out.min()) == iters
         gr.close()
-        return sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+        return med, best
 
-    all_symmetric = int(solver.check_symmetric(n, N, B, S).min()) == 1 and int(solver.check_symmetric(n, N, B, P).min()) == 1
-    sym_ms = time_mode(1, args.steps)   # symmetric kernel alone (no device check): the dominant kernel
-    gen_ms = time_mode(0, args.steps)   # general kernel (always reads L): the reference-equivalent stream
-    pcg_gbps = pcg_bytes / (sym_ms * 1e-3) / 1e9
-    gen_gbps = pcg_bytes / (gen_ms * 1e-3) / 1e9
-    resident = B * (2 * (2 * N - 1) * n * n + 5 * n * N) * 4   # [D|R] of both matrices once per solve + vectors
-
+    all_symmetric = (int(solver.check_symmetric(n, N, B, S).min()) == 1
+                     and int(solver.check_symmetric(n, N, B, P).min()) == 1)
+    REPS = max(100, args.steps)
+    sym_ms, sym_best = time_mode(1, REPS)   # the dominant kernel alone (caller asserts symmetry: no check launch)
+    flops = pcg_flops_per_launch(n, N, B, iters)
+    pcg_bytes = pcg_bytes_per_launch(n, N, B, iters, 4)
+    resident_bytes = B * (2 * (2 * N - 1) * n * n + 5 * n * N) * 4   # [D|R] of both matrices once per solve + vectors
+    tflops = flops / (sym_ms * 1e-3) / 1e12
+    sq = pmc_valu("pcg_resident_sym_kernel")
+    out = None
     if rank == 0:
+        # Phi^-1 operand accounting of the resident kernel ("LDS hit rate for the preconditioner", north star):
+        # [D|R] of Phi^-1 is consumed (iters + 1) times per solve and fetched from HBM once; on chip, block-rows
+        # k1 = 2j+1 live in LDS whole and P0_LDS_QUADS = 2 of the 14 pieces of block-rows k0 = 2j as well.
+        lds_share = (14 + 2) / 28.0
         out = {
-            "metric": "PCG iterations/sec and GB/s on block-tridiag SpMV, stateSize\u00d7knotPoints",
+            "metric": "PCG iterations/sec and GB/s on block-tridiag SpMV, stateSize×knotPoints",
             "value": total_units / elapsed,
             "unit": "iter/s",
             "n_gpus": world,
@@ -253,51 +336,215 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: stateSize=14 knotPoints=128 fp32 batch=1024 per GPU, "
-                                   "25 fixed PCG iterations per step (exit_tol=0), symmetric-stair Pinv formed on the device, "
-                                   "hipGraph replay",
-                       "stateSize": n, "knotPoints": N, "batch_per_gpu": B, "pcg_iters_per_step": iters,
-                       "path": "fused (one workgroup per problem); default symmetric mode 2: device check of L_{k+1} == R_k^T, "
-                               "then the symmetric halves of S and Pinv stay resident on the CU (registers + LDS) for the whole solve",
-                       "graph_ms_per_step": step_ms, "sharding": f"batch x{world}, no data-path collective"},
-            "solves_per_sec": world * B * args.steps / elapsed,
-            "spmv_GBps": sp_gbps,
+            "config": {"workload": "BASELINE configs[2]: stateSize=14 knotPoints=128 fp32 batch=1024 per GPU "
+                                   "(configs[4] at 8 GPUs), 25 fixed PCG iterations per step (exit_tol=0), problems "
+                                   "Gen(14,128,1234+i,0.5), symmetric-stair Pinv formed on the device, hipGraph replay",
+                       "stateSize": n, "knotPoints": N, "batch_per_gpu": BATCH_PER_GPU, "global_batch": total_batch,
+                       "pcg_iters_per_step": iters,
+                       "path": "default (symmetric mode 2): device check of L_{k+1} == R_k^T, then [D|R] of S and Pinv "
+                               "stay resident on the CU (registers + LDS) for the whole solve",
+                       "graph_ms_per_step_median": step_ms,
+                       "sharding": f"problems [g*{BATCH_PER_GPU}, (g+1)*{BATCH_PER_GPU}) on rank g of {world}, seeds 1234+i, "
+                                   "no data-path collective; RCCL all_reduce of (max elapsed, sum units) only"},
+            "solves_per_sec": total_batch * args.steps / elapsed,
             "value_definition": "problem-iterations per second (25 PCG iterations x 1024 problems per GPU per step), default path",
-            "roofline": {"bound": "hbm", "kernel": "pcg_resident_sym_kernel<14,true> (symmetric matrices resident on the CU)",
-                         "achieved": pcg_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": pcg_gbps / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("pcg_resident_sym_kernel"),
-                         "algorithmic_bytes_per_launch": pcg_bytes, "kernel_ms": sym_ms,
-                         "bytes_moved_per_launch": resident, "achieved_moved": resident / (sym_ms * 1e-3) / 1e9,
-                         "all_problems_symmetric": all_symmetric,
-                         "note": "achieved = SURVEY 8d algorithmic bytes (S and Pinv in full, once per iteration) / kernel "
-                                 "time. The default path tests L_{k+1} == R_k^T on the device; for problems that pass, "
-                                 "[D|R] of both matrices (401 KB) is loaded ONCE per solve into the registers and LDS of "
-                                 "one CU and the iterations move no matrix bytes at all (bytes_moved_per_launch), hence "
-                                 "frac >> 1: the kernel is bound by VALU issue and on-chip latency, not by HBM. "
-                                 "general_kernel is the reference-equivalent stream (reads L every iteration)."},
-            "general_kernel": {"kernel": "pcg_fused_kernel<float,14,2,8,false> (gbdpcg_set_symmetric(0): always reads L)",
-                               "achieved": gen_gbps, "unit": "GB/s", "frac": gen_gbps / HBM_PEAK_GBPS, "kernel_ms": gen_ms,
-                               "traffic": pmc_traffic("pcg_fused_kernel<float,14,2,8,false>"),
-                               "problem_iters_per_sec_one_gpu": B * iters / (gen_ms * 1e-3)},
-            "spmv": {"bound": "hbm", "kernel": "spmv_kernel<float,14,2,4>", "achieved": sp_gbps,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sp_gbps / HBM_PEAK_GBPS,
-                     "frac_of_copy_ceiling": sp_gbps / HBM_COPY_CEIL_GBPS,
-                     "frac_of_cold_read_ceiling": sp_gbps / HBM_COLD_READ_GBPS,
-                     "traffic": pmc_traffic("spmv_kernel<float,14"),
-                     "algorithmic_bytes_per_launch": spmv_bytes_per_launch(n, N, B, 4), "kernel_ms": sp_ms},
-            "spmv_symmetric": {"kernel": "spmv_sym_kernel<float,14,4> (gbdpcg_set_symmetric(1): reads [D|R] only)",
-                               "achieved": sps_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sps_gbps / HBM_PEAK_GBPS,
-                               "traffic": pmc_traffic("spmv_sym_kernel<float,14"), "kernel_ms": sps_ms,
-                               "bytes_streamed_per_launch": B * ((2 * N - 1) * n * n + 2 * n * N) * 4},
+            "roofline": {
+                "bound": "valu",
+                "kernel": "pcg_resident_sym_kernel<14,true> (symmetric S and Pinv resident on the CU; timed alone, "
+                          "gbdpcg_set_symmetric(1))",
+                "achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "traffic": pmc_traffic("pcg_resident_sym_kernel"),
+                "flops_per_launch": flops,
+                "kernel_ms": sym_ms, "kernel_ms_min": sym_best, "replays": REPS, "statistic": "median",
+                "valu_issue": sq,
+                "hbm_share": {"bytes_moved_per_launch": resident_bytes,
+                              "achieved_GBps": resident_bytes / (sym_ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": resident_bytes / (sym_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "equivalent_stream_rate": {"algorithmic_bytes_per_launch": pcg_bytes,
+                                           "GBps": pcg_bytes / (sym_ms * 1e-3) / 1e9,
+                                           "note": "SURVEY 8d bytes (S and Pinv in full, once per iteration) / kernel time: "
+                                                   "what a streaming kernel would have to sustain to match; not an HBM rate"},
+                "all_problems_symmetric": all_symmetric,
+                "note": "peak = fp32 vector peak (= dense fp32 MFMA peak) of MI355X_MICROARCH.md; the matrices are read once "
+                        "per solve, so the kernel is bound by VALU issue and on-chip latency, not by HBM"},
+            "pinv_onchip": {"hit_rate": iters / (iters + 1.0), "from_lds": lds_share, "from_registers": 1.0 - lds_share,
+                            "definition": "Phi^-1 bytes consumed by the (iters+1) products of a solve that are served from "
+                                          "the CU (LDS or registers) / bytes consumed; from_lds + from_registers split the "
+                                          "on-chip part (kernel geometry, pcg_resident_sym.hip)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, N, iters)
-        print(json.dumps(out), flush=True)
+
+    if world == 1:
+        gen_ms, _ = time_mode(0, 30)        # general kernel (always reads L): the reference-equivalent stream
+        gen_gbps = pcg_bytes / (gen_ms * 1e-3) / 1e9
+        out["general_kernel"] = {
+            "kernel": "pcg_fused_kernel<float,14,2,8,false> (gbdpcg_set_symmetric(0): always reads L)",
+            "bound": "hbm+mall", "achieved": gen_gbps, "unit": "GB/s", "frac": gen_gbps / HBM_PEAK_GBPS, "kernel_ms": gen_ms,
+            "traffic": pmc_traffic("pcg_fused_kernel<float,14,2,8,false>"),
+            "problem_iters_per_sec_one_gpu": B * iters / (gen_ms * 1e-3),
+            "note": "algorithmic bytes / time; the in-flight set is re-read every iteration, so part is served by the "
+                    "256 MiB Infinity Cache: not an HBM-only statement"}
+
+        # standalone SpMV over FOUR distinct 308 MB matrices in rotation (1.23 GB: the 256 MiB Infinity Cache
+        # cannot hold anything between two uses of the same line), each launch bracketed by its own event pair
+        mats = [S, P, S.clone(), P.clone()]
+        x = torch.randn_like(gamma)
+        y = torch.empty_like(gamma)
+
+        def time_spmv(launches=104, rounds=3):
+            res = []
+            for _ in range(rounds):
+                evs = new_events(launches)
+                torch.cuda.synchronize()
+                for k, (e0, e1) in enumerate(evs):
+                    e0.record(stream)
+                    solver.spmv(n, N, B, mats[k % 4], x, y)
+                    e1.record(stream)
+                torch.cuda.synchronize()
+                res.append(median([e0.elapsed_time(e1) for e0, e1 in evs[4:]]))
+            return median(res)
+
+        sp_bytes = spmv_bytes_per_launch(n, N, B, 4)
+        sp_ms = time_spmv()
+        sp_gbps = sp_bytes / (sp_ms * 1e-3) / 1e9
+        # the same kernel when consecutive launches alternate between only two matrices (616 MB): what the
+        # Infinity Cache adds
+        mats2 = mats
+        mats = [S, P, S, P]
+        sp2_ms = time_spmv()
+        mats = mats2
+        solver.set_symmetric(1)   # only [D|R] is read (caller's word: a device check would cost as much as the product)
+        sps_ms = time_spmv()
+        solver.set_symmetric(2)
+        del mats, mats2
+        out["spmv_GBps"] = sp_gbps
+        out["spmv"] = {"bound": "hbm", "kernel": "spmv_kernel<float,14,2,4>", "achieved": sp_gbps,
+                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sp_gbps / HBM_PEAK_GBPS,
+                       "frac_of_copy_ceiling": sp_gbps / HBM_COPY_CEIL_GBPS,
+                       "frac_of_cold_read_ceiling": sp_gbps / HBM_COLD_READ_GBPS,
+                       "traffic": pmc_traffic("spmv_kernel<float,14"),
+                       "algorithmic_bytes_per_launch": sp_bytes, "kernel_ms": sp_ms, "statistic": "median of 100 launches x 3 rounds",
+                       "rotation": "4 matrices x 308 MB = 1.23 GB (Infinity Cache cannot serve it)",
+                       "two_matrix_rotation": {"kernel_ms": sp2_ms, "GBps": sp_bytes / (sp2_ms * 1e-3) / 1e9,
+                                               "note": "616 MB rotation, as in round 1: includes Infinity-Cache hits"}}
+        out["spmv_symmetric"] = {"kernel": "spmv_sym_kernel<float,14,4> (gbdpcg_set_symmetric(1): reads [D|R] only)",
+                                 "achieved": sp_bytes / (sps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": sp_bytes / (sps_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 "traffic": pmc_traffic("spmv_sym_kernel<float,14"), "kernel_ms": sps_ms,
+                                 "bytes_streamed_per_launch": B * ((2 * N - 1) * n * n + 2 * n * N) * 4,
+                                 "frac_streamed": B * ((2 * N - 1) * n * n + 2 * n * N) * 4 / (sps_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     graph.close()
+    del S, P, gamma, lam, r, p
+    torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_configs:
+        out["configs"] = bench_configs(solver, torch, binding, synth, dev, stream)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, N, iters)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
     solver.close()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_configs(solver, torch, binding, synth, dev, stream):
+    """The other single-GPU BASELINE configs, each with the bound it has: C2 (n=14, N=64, fp32, one problem), C4
+    (n=36, N=256, fp64, one problem), C5's 8192-problem batch on one GPU.  hipGraph replay, median of per-replay
+    HIP-event times; 'fixed25' = exit_tol 0 / 25 iterations, 'converged' = tol 1e-6."""
+    res = {}
+
+    def new_events(k):
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+
+    for name, n, N, B, dt, reps in (("C2", 14, 64, 1, torch.float32, 100), ("C4", 36, 256, 1, torch.float64, 100),
+                                    ("C5_on_one_gpu", 14, 128, 8192, torch.float32, 20)):
+        es = 4 if dt == torch.float32 else 8
+        g = synth.gen_torch_seeded(n, N, 0, B, dev, dt, seed=BASE_SEED)
+        S, gamma = g["S"], g["gamma"]
+        del g
+        P = solver.form_pinv(n, N, B, S, binding.PINV_STAIR)
+        lam = torch.zeros_like(gamma)
+        r, p = torch.empty_like(gamma), torch.empty_like(gamma)
+        it = torch.zeros(B, dtype=torch.int32, device=dev)
+        fl = torch.zeros(B, dtype=torch.uint8, device=dev)
+        rec = {"stateSize": n, "knotPoints": N, "batch": B, "dtype": "f32" if es == 4 else "f64",
+               "path": {binding.PATH_FUSED: "fused", binding.PATH_SPLIT: "split"}.get(solver.choose_path(es, n, N, B), "auto")}
+        times = {}
+        for tag, tol in (("fixed25", 0.0), ("converged", 1e-6)):
+            gr = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, tol, MAX_ITER, it, fl)
+            it.fill_(-1)
+            for _ in range(5):
+                lam.zero_()
+                gr.launch(stream)
+            evs = new_events(reps)
+            torch.cuda.synchronize()
+            for e0, e1 in evs:
+                lam.zero_()
+                e0.record(stream)
+                gr.launch(stream)
+                e1.record(stream)
+            torch.cuda.synchronize()
+            assert int(it.min()) >= 1 and bool(torch.isfinite(lam).all()), "the timed replays did not solve anything"
+            times[tag] = (median([a.elapsed_time(b) for a, b in evs]) * 1e3, float(it.float().mean()))
+            gr.close()
+        (t25, i25), (tc, ic) = times["fixed25"], times["converged"]
+        iter_bytes = 2 * (3 * N - 2) * n * n * es          # SURVEY 8d: S and Pinv once per iteration, per problem
+        floor_us = iter_bytes * B / (HBM_PEAK_GBPS * 1e9) * 1e6
+        us_iter = (t25 - tc) / max(i25 - ic, 1.0)          # marginal cost of one more iteration
+        rec.update({"us_per_solve_fixed25": t25, "us_per_solve_converged": tc, "iters_converged": ic,
+                    "us_per_iteration": us_iter, "us_per_iteration_fixed25_incl_launch": t25 / i25,
+                    "problem_iters_per_sec": B * i25 / (t25 * 1e-6),
+                    "hbm_floor_us_per_iteration": floor_us, "frac_of_hbm_floor": floor_us / us_iter,
+                    "statistic": f"median of {reps} graph replays"})
+        if B == 1:
+            rec["bound"] = ("latency: one problem, matrices resident on chip for the whole solve; the HBM floor is the "
+                            "section-8d stream time and is reported for completeness")
+        else:
+            tf = pcg_flops_per_launch(n, N, B, MAX_ITER) / (t25 * 1e-6) / 1e12
+            rec["bound"] = "valu (resident symmetric kernel, as the headline)"
+            rec["tflops"] = tf
+            rec["frac_of_fp32_peak"] = tf / FP32_VECTOR_PEAK_TFLOPS
+        res[name] = rec
+        del S, P, gamma, lam, r, p
+        torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="host logic only (rendezvous, sharding, aggregation) with gloo and no GPU; reports no value")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        if args.gpus > 1:
+            launch_ranks(args.gpus)      # parent: no GPU call before or after
+            return
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(world_env)
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                     f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) "
+                     f"or run `python bench.py --gpus {args.gpus}` without a torch.distributed environment")
+    if args.dry_run:
+        run_dry(args, world, rank)
+    else:
+        run_rank(args, world, rank, local_rank)
 
 
 if __name__ == "__main__":

@@ -75,6 +75,31 @@ gbdpcg_status fail(gbdpcg_handle_t h, hipError_t e)
         if (e__ != hipSuccess) return fail((h), e__);   \
     } while (0)
 
+// Every entry point runs with the handle's device current and puts the caller's device back on return (a host
+// thread that loops over the handles of several GPUs keeps whatever device it had selected).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceScope()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define DEVICE_SCOPE(h)                          \
+    DeviceScope device_scope__((h)->dev.device); \
+    if (device_scope__.err != hipSuccess) return fail((h), device_scope__.err)
+
 bool shape_ok(uint32_t n, uint32_t N, uint32_t batch)
 {
     if (n == 0 || N == 0 || batch == 0) return false;
@@ -156,7 +181,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED) {
         const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
         if (has_sym && h->symmetric == 2 && given_verdict_stride) {
@@ -235,7 +260,7 @@ gbdpcg_status spmv_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batc
 {
     if (!h || !d_M || !d_x || !d_y || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     SpmvArgs<T> a{d_M, d_x, d_y, n, N, batch};
     a.symmetric = h->symmetric == 1;  // a check would cost as much as the product itself
     HIP_TRY(h, launch_spmv<T>(h->dev, a, stream));
@@ -262,7 +287,7 @@ gbdpcg_status form_pinv_solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, ui
         (int)kind > 2)
         return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     uint32_t stride = 0;
     if (h->symmetric == 2 && pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED &&
         fused_has_symmetric<T>(h->dev, n, N, batch))
@@ -310,7 +335,7 @@ gbdpcg_status solve_host_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, const T
                               uint8_t *h_exit)
 {
     if (!h || !h_S || !h_gamma || !h_lambda || !shape_ok(n, N, 1)) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     const size_t mbytes = (size_t)3 * n * n * N * sizeof(T), vbytes = (size_t)n * N * sizeof(T);
     // one allocation: S | Pinv | gamma | lambda (256-byte aligned pieces)
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -350,7 +375,7 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     if (!h || !out) return GBDPCG_ERR_INVALID;
     *out = nullptr;
     if (!shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
@@ -443,7 +468,8 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     // 64 KiB default window; larger dynamic sizes are opted into per kernel with hipFuncSetAttribute)
     h->dev.lds_per_cu = 160 * 1024;
     h->dev.lds_per_wg_max = 160 * 1024;
-    hipError_t e = hipSetDevice(device);
+    DeviceScope scope(device);
+    hipError_t e = scope.err;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
     if (e == hipSuccess) {
         h->d_exit = reinterpret_cast<uint8_t *>(h->d_iters) + 128;
@@ -469,7 +495,7 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
 gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
 {
     if (!h) return GBDPCG_ERR_INVALID;
-    (void)hipSetDevice(h->dev.device);
+    DeviceScope scope(h->dev.device);
     if (h->ws) (void)hipFree(h->ws);
     if (h->sym_flags) (void)hipFree(h->sym_flags);
     for (void *old : h->retired) (void)hipFree(old);
@@ -518,7 +544,7 @@ gbdpcg_status gbdpcg_check_symmetric_f32(gbdpcg_handle_t h, uint32_t n, uint32_t
                                          uint8_t *d_flags, void *stream)
 {
     if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     hipError_t cerr = hipSuccess;
     if (launch_check_symmetric_pair<float>(n, N, batch, d_M, nullptr, d_flags, (hipStream_t)stream, &cerr)) {
         HIP_TRY(h, cerr);
@@ -531,7 +557,7 @@ gbdpcg_status gbdpcg_check_symmetric_f64(gbdpcg_handle_t h, uint32_t n, uint32_t
                                          uint8_t *d_flags, void *stream)
 {
     if (!h || !d_M || !d_flags || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     hipError_t cerr = hipSuccess;
     if (launch_check_symmetric_pair<double>(n, N, batch, d_M, nullptr, d_flags, (hipStream_t)stream, &cerr)) {
         HIP_TRY(h, cerr);
@@ -563,7 +589,7 @@ gbdpcg_status gbdpcg_check_occupancy(gbdpcg_handle_t h, uint32_t elem_size, uint
     if (fits) return GBDPCG_OK;
     if ((size_t)3 * n * elem_size + 64 * elem_size > h->dev.lds_per_wg_max) return GBDPCG_ERR_TOO_LARGE;
     size_t free_b = 0, total_b = 0;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
     const size_t need = gbdpcg_workspace_bytes(h, elem_size, n, N, batch);
     return need <= h->ws_bytes || need <= free_b ? GBDPCG_OK : GBDPCG_ERR_TOO_LARGE;  // growth keeps the old buffer
@@ -583,7 +609,7 @@ size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n,
 gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
 {
     if (!h || (elem_size != 4 && elem_size != 8) || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     // the verdict bytes of the device symmetry check (mode 2) must exist before a capture as well
     gbdpcg_status st = ensure_sym_flags(h, elem_size == 8 ? verdict_bytes<double>(n, N, batch) : verdict_bytes<float>(n, N, batch));
     if (st != GBDPCG_OK) return st;
@@ -670,6 +696,7 @@ gbdpcg_status gbdpcg_graph_create_solve_f64(gbdpcg_handle_t h, uint32_t n, uint3
 gbdpcg_status gbdpcg_graph_launch(gbdpcg_graph_t g, void *stream)
 {
     if (!g || !g->exec) return GBDPCG_ERR_INVALID;
+    DEVICE_SCOPE(g->h);
     HIP_TRY(g->h, hipGraphLaunch(g->exec, (hipStream_t)stream));
     return GBDPCG_OK;
 }
@@ -687,7 +714,7 @@ gbdpcg_status gbdpcg_form_pinv_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, ui
                                    float *d_Pinv, gbdpcg_pinv_kind kind, void *stream)
 {
     if (!h || !d_S || !d_Pinv || !shape_ok(n, N, batch) || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     HIP_TRY(h, launch_form_pinv<float>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, (hipStream_t)stream));
     return GBDPCG_OK;
 }
@@ -695,7 +722,7 @@ gbdpcg_status gbdpcg_form_pinv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, ui
                                    double *d_Pinv, gbdpcg_pinv_kind kind, void *stream)
 {
     if (!h || !d_S || !d_Pinv || !shape_ok(n, N, batch) || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->dev.device));
+    DEVICE_SCOPE(h);
     HIP_TRY(h, launch_form_pinv<double>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, (hipStream_t)stream));
     return GBDPCG_OK;
 }

@@ -592,13 +592,10 @@ bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStre
         static const bool no_staging = getenv("GBDPCG_RS_DIRECT_LOADS") != nullptr;  // tuning runs only
         const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
         auto kern = staged ? pcg_resident_sym_kernel<14, true> : pcg_resident_sym_kernel<14, false>;
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[staged]) {
-            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)dev.lds_per_wg_max);
-            if (*err != hipSuccess) return true;
-            attr_set[staged] = true;
-        }
+        // on every launch, like the other launchers: HIP keeps the attribute per device, and a process may hold
+        // handles on several devices (one host thread each)
+        *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (*err != hipSuccess) return true;
         uint32_t grid = (uint32_t)dev.num_cus;  // one workgroup owns a CU's register file and most of its LDS
         if (grid > a.batch) grid = a.batch;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SymResGeom<14>::THREADS), lds, s, a);

@@ -73,6 +73,24 @@ template <typename T> static void run(const char *prec)
         gpuErrchk(hipMemcpy(r, d_r, sizeof r, hipMemcpyDeviceToHost));
         snprintf(tag, sizeof tag, "%s device_resid", prec);
         report(tag, it, r);
+        // stair preconditioner formed on the device, read back and printed: the test runs the oracle on exactly
+        // this Pinv (the one the device solve used), so the iteration counts can be compared for equality
+        gbdpcg_handle_t h = gbdpcg_detail::handle();
+        if constexpr (sizeof(T) == 4) {
+            GBDPCG_CHECK(gbdpcg_form_pinv_f32(h, n, N, 1, (const float *)d_S, (float *)d_P, GBDPCG_PINV_STAIR, nullptr), "form_pinv");
+        } else {
+            GBDPCG_CHECK(gbdpcg_form_pinv_f64(h, n, N, 1, (const double *)d_S, (double *)d_P, GBDPCG_PINV_STAIR, nullptr), "form_pinv");
+        }
+        gpuErrchk(hipMemset(d_l, 0, sizeof h_gamma));
+        it = solvePCG<T>(n, N, d_S, d_P, d_g, d_l, d_r, d_p, d_v, d_e, &cfg);
+        gpuErrchk(hipMemcpy(lam, d_l, sizeof lam, hipMemcpyDeviceToHost));
+        snprintf(tag, sizeof tag, "%s device_stair", prec);
+        report(tag, it, lam);
+        T Pback[36];
+        gpuErrchk(hipMemcpy(Pback, d_P, sizeof Pback, hipMemcpyDeviceToHost));
+        printf("%s device_stair_pinv=", prec);
+        for (int i = 0; i < 36; ++i) printf("%.17g ", (double)Pback[i]);
+        printf("\n");
         for (T *q : {d_S, d_P, d_g, d_l, d_r, d_p, d_v, d_e}) gpuErrchk(hipFree(q));
     }
     {   // CSR overload: dense-ish CSR of the same matrix (zeros of the pattern included)

@@ -123,6 +123,100 @@ def gen_numpy(n: int, N: int, seed: int = 1234, a: float = 0.5, batch: int = 1,
                 gamma=np.stack(g_all).astype(dtype))
 
 
+def _torch_splitmix64(x):
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap = uint64 arithmetic; logical shifts
+    spelled as arithmetic shift + mask)."""
+    def s64(c):  # uint64 constant -> the int64 with the same bits
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def shr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    x = x + s64(0x9E3779B97F4A7C15)
+    z = (x ^ shr(x, 30)) * s64(0xBF58476D1CE4E5B9)
+    z = (z ^ shr(z, 27)) * s64(0x94D049BB133111EB)
+    return z ^ shr(z, 31)
+
+
+def normals_torch(seeds, stream: int, count: int, device):
+    """normals(seed, stream, count) for every seed of `seeds` at once, as a [len(seeds), count] fp64 tensor on
+    `device`: the same counter-based words as the numpy generator (identical 53-bit uniforms; log / cos / sqrt
+    of the device's libm, so the normals agree to rounding, not to the bit)."""
+    import math
+    import torch
+    with np.errstate(over="ignore"):
+        keys = _splitmix64(np.asarray(seeds, dtype=np.uint64) * _U64(0x632BE59BD9B4E019)
+                           + _U64(stream) * _U64(0xD1342543DE82EF95))
+    key = torch.from_numpy(keys.view(np.int64).copy()).to(device)[:, None]
+    ctr = torch.arange(2 * count, dtype=torch.int64, device=device)[None, :]
+    w = _torch_splitmix64(key + ctr * (0x9E3779B97F4A7C15 - (1 << 64)))
+    u = (((w >> 11) & ((1 << 53) - 1)).to(torch.float64) + 0.5) * (1.0 / 9007199254740992.0)
+    u1, u2 = u[:, :count], u[:, count:]
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+
+
+def _qr_q_positive(A):
+    """Q factor of the unique QR (diag(R) > 0) of every n x n matrix of A [..., n, n]: n batched Householder
+    reflections (elementwise + bmm work only; torch.linalg.qr on the GPU launches several kernels per matrix)."""
+    import torch
+    n = A.shape[-1]
+    R = A.clone()
+    Q = torch.eye(n, dtype=A.dtype, device=A.device).expand(A.shape).clone()
+    for j in range(n):
+        x = R[..., j:, j]
+        nrm = x.norm(dim=-1, keepdim=True)
+        sgn = torch.where(x[..., :1] < 0, -torch.ones_like(nrm), torch.ones_like(nrm))
+        v = x.clone()
+        v[..., :1] += sgn * nrm                     # v = x + sign(x0) |x| e0
+        v = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-300)
+        v = v.unsqueeze(-1)                         # [..., n-j, 1]
+        R[..., j:, :] -= 2.0 * v @ (v.transpose(-1, -2) @ R[..., j:, :])
+        Q[..., :, j:] -= 2.0 * (Q[..., :, j:] @ v) @ v.transpose(-1, -2)
+    d = torch.diagonal(R, dim1=-2, dim2=-1)
+    sg = torch.where(d < 0, -torch.ones_like(d), torch.ones_like(d))
+    return Q * sg.unsqueeze(-2)
+
+
+def gen_torch_seeded(n: int, N: int, lo: int, hi: int, device, dtype, seed: int = 1234, a: float = 0.5,
+                     chunk: int = 256):
+    """Problems lo .. hi-1 of the batch Gen(n, N, seed + i, a) -- SURVEY.md section 8d: problem i depends on
+    seed + i only, whatever the rank or world size that generates it -- built on `device` with torch ops from
+    the same counter-based random words as gen_numpy (same construction; equal to gen_numpy to fp64 rounding).
+    Returns flat S [hi-lo, 3n^2N] and gamma [hi-lo, nN] in `dtype`, and Pinv (host-formula symmetric stair)."""
+    import torch
+    cnt = hi - lo
+    S = torch.empty((cnt, N * 3 * n * n), device=device, dtype=dtype)
+    P = torch.empty_like(S)
+    gamma = torch.empty((cnt, N * n), device=device, dtype=dtype)
+    eye = torch.eye(n, device=device, dtype=torch.float64)
+
+    def pack(L, D, R):
+        blk = torch.stack([L, D, R], dim=-3).transpose(-1, -2)
+        return blk.reshape(blk.shape[0], -1)
+
+    for c0 in range(0, cnt, chunk):
+        b = min(chunk, cnt - c0)
+        seeds = [seed + lo + c0 + i for i in range(b)]
+        Mk = normals_torch(seeds, 1, N * n * n, device).reshape(b, N, n, n) / np.sqrt(n)
+        gam = normals_torch(seeds, 2, N * n, device)
+        W = eye + Mk @ Mk.transpose(-1, -2)
+        D = W.clone()
+        L = torch.zeros_like(W)
+        if N > 1:
+            A = normals_torch(seeds, 0, (N - 1) * n * n, device).reshape(b, N - 1, n, n)
+            Q = _qr_q_positive(A)
+            QW = Q @ W[:, :-1]
+            D[:, 1:] += (a * a) * (QW @ Q.transpose(-1, -2))
+            L[:, 1:] = -a * QW
+        D = 0.5 * (D + D.transpose(-1, -2))
+        R = torch.zeros_like(W)
+        if N > 1:
+            R[:, :-1] = L[:, 1:].transpose(-1, -2)
+        S[c0:c0 + b] = pack(L, D, R).to(dtype)
+        P[c0:c0 + b] = pack(*stair_pinv_blocks(L, D, R, xp=torch)).to(dtype)
+        gamma[c0:c0 + b] = gam.to(dtype)
+    return dict(n=n, N=N, batch=cnt, S=S, Pinv=P, gamma=gamma)
+
+
 def gen_torch(n: int, N: int, batch: int, device, dtype, seed: int = 1234, a: float = 0.5,
               chunk: int = 256):
     """Same construction on `device` with torch ops (torch RNG).  Returns flat tensors

@@ -70,7 +70,10 @@ typedef enum gbdpcg_pinv_kind {
  * words, the split path's workspace, the per-problem symmetry flags) that every solve and every graph
  * created through it uses, so two solves issued through the same handle must not overlap in time
  * (same stream, or otherwise ordered).  `device` is a HIP ordinal.  Replaces the per-call
- * cudaMalloc/cudaFree of interface.cuh:105-108,140-141. */
+ * cudaMalloc/cudaFree of interface.cuh:105-108,140-141.
+ * A process may hold handles on several devices (one host thread per handle, or one thread looping over
+ * them): every entry point makes the handle's device current for the duration of the call and restores the
+ * caller's current device before it returns.  Streams and pointers passed in must belong to the handle's device. */
 gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device);
 gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h);
 

@@ -86,24 +86,28 @@ inline void gpuAssert(hipError_t code, const char *file, int line, bool abort = 
 
 namespace gbdpcg_detail {
 
-// One library handle per host thread, created on first use.
+// One library handle per host thread AND per device, created on first use: the handle of the device that is
+// current at the call (as the reference launches on whatever device is current, interface.cuh:132), so a
+// thread that loops hipSetDevice(g) over the GPUs of a node gets the right handle for the pointers it passes.
 inline gbdpcg_handle_t handle()
 {
     struct Holder {
-        gbdpcg_handle_t h = nullptr;
-        ~Holder() { if (h) gbdpcg_destroy(h); }
+        std::vector<gbdpcg_handle_t> by_device;
+        ~Holder() { for (gbdpcg_handle_t h : by_device) if (h) gbdpcg_destroy(h); }
     };
     thread_local Holder holder;
-    if (!holder.h) {
-        int dev = 0;
-        gpuErrchk(hipGetDevice(&dev));
-        gbdpcg_status st = gbdpcg_create(&holder.h, dev);
+    int dev = 0;
+    gpuErrchk(hipGetDevice(&dev));
+    if ((size_t)dev >= holder.by_device.size()) holder.by_device.resize((size_t)dev + 1, nullptr);
+    gbdpcg_handle_t &h = holder.by_device[(size_t)dev];
+    if (!h) {
+        gbdpcg_status st = gbdpcg_create(&h, dev);
         if (st != GBDPCG_OK) {
             fprintf(stderr, "GBD-PCG: cannot create solver on device %d: %s\n", dev, gbdpcg_status_string(st));
             exit(static_cast<int>(st));
         }
     }
-    return holder.h;
+    return h;
 }
 
 // C-ABI status -> the reference's error convention (print, exit with the code).

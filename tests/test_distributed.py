@@ -67,3 +67,42 @@ def test_two_rank_gloo_aggregation():
     elapsed, total, want = out.get(timeout=5)
     assert elapsed == 2.0          # max over ranks
     assert total == want           # shards together did exactly the work of the whole batch
+
+
+def test_seeded_generator_is_rank_independent():
+    """bench.py builds rank g's shard with synth.gen_torch_seeded(lo, hi): problem i must be Gen(n, N, 1234 + i)
+     whatever slice it is generated in -- equal to the canonical numpy generator to fp64
+    rounding, and identical between two different slicings of the same batch."""
+    from gbd_pcg_amd import synth
+    n, N, B = 14, 9, 6
+    ref = synth.gen_numpy(n, N, seed=1234, batch=B, dtype=np.float64)
+    whole = synth.gen_torch_seeded(n, N, 0, B, "cpu", torch.float64, seed=1234, chunk=4)
+    parts = [synth.gen_torch_seeded(n, N, lo, hi, "cpu", torch.float64, seed=1234)
+             for lo, hi in (sharding.shard_range(B, r, 4) for r in range(4)) if hi > lo]
+    for key in ("S", "Pinv", "gamma"):
+        got = whole[key].numpy()
+        assert np.abs(got - ref[key]).max() <= 1e-12 * np.abs(ref[key]).max(), key
+        assert np.array_equal(np.concatenate([p[key].numpy() for p in parts]), got), key
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus 2` with no torch.distributed environment must itself start two fresh ranks
+    (rendezvous over gloo here: --dry-run exercises the launcher, sharding and aggregation without a GPU and
+    reports no metric value).  The line rank 0 prints carries the ranks the process group saw."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["dry_run"] is True and rec["value"] is None
+    assert rec["n_gpus"] == 2 and rec["shards"] == [[0, 1024], [1024, 2048]]
+    assert len(set(rec["pids"])) == 2 and os.getpid() not in rec["pids"]
+    assert rec["max_elapsed"] == 2.0 and rec["total_units"] == 2 * 1024 * 25 * 3
+    # a rank count that contradicts the environment is an error, not a silent one-rank run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
+                         capture_output=True, text=True, timeout=60, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr

@@ -51,12 +51,31 @@ def test_selftest_against_oracle(orc):
     it, res = rec["f64 device_resid"]
     assert np.linalg.norm(res - o_id["r"]) < 1e-9 * np.linalg.norm(gamma)
 
-    # fp32: kappa ~ 1562, answers agree to ~1e-5; iteration count with Pinv = I is order-sensitive
+    # device-formed stair Pinv, read back: the oracle runs on EXACTLY the preconditioner the device solve used, in the
+    # device's precision, so the iteration counts are compared for equality (L_0 / R_{N-1} of the read-back are never
+    # used, pcg.cuh:105-106)
+    pinv = {}
+    for line in out.splitlines():
+        if " device_stair_pinv=" in line:
+            prec, vals = line.split(" device_stair_pinv=")
+            pinv[prec] = np.array([float(v) for v in vals.split()])
+    for prec, dt, tol in (("f64", np.float64, 1e-10), ("f32", np.float32, 2e-5)):
+        P_dev = np.nan_to_num(pinv[prec]).astype(dt)
+        o_dev = orc.pcg(n, N, S.astype(dt), P_dev, gamma.astype(dt), tol=1e-6, max_iter=25)
+        it, lam = rec[f"{prec} device_stair"]
+        assert it == o_dev["iters"], (prec, it, o_dev["iters"])
+        assert np.linalg.norm(lam - o_dev["lambda_"]) / np.linalg.norm(o_dev["lambda_"]) < tol
+        it_h, lam_h = rec[f"{prec} host_stair"]      # the host overload forms the same Pinv: same count, same answer
+        assert it_h == it and np.array_equal(lam_h, lam)
+
+    # fp32, Pinv = I: kappa(S) ~ 1562 and no preconditioner -- the exit iteration depends on the summation order
+    # (the reference compiled for the host takes 9, a numpy restatement 8; the oracle's own
+    # FMA / tree-order variants bracket it), so the GPU count has to be one some summation order produces
+    S32, g32 = S.astype(np.float32), gamma.astype(np.float32)
+    counts = {int(orc.pcg(n, N, S32, None, g32, tol=1e-6, max_iter=25, flags=f)["iters"]) for f in range(4)} | {8, 9}
     for tag in ("host_ident", "pcg_solve", "device_ident", "csr_ident"):
         it, lam = rec[f"f32 {tag}"]
-        assert it in (8, 9) and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 2e-4
-    it, lam = rec["f32 host_stair"]   # Pinv formed in fp32 on the device: 3 or 4
-    assert it in (3, 4) and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 5e-5
+        assert it in counts and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 2e-4
 
 
 @pytest.mark.parametrize("exe", ["pcg_solve", "pcg_solve_dp"])

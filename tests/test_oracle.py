@@ -174,3 +174,19 @@ def test_survey_iteration_counts(golden_dir):
     for name, want in (("gen_14x64", 9), ("gen_14x128", 9), ("gen_36x256", 10)):
         G = np.load(os.path.join(golden_dir, name + ".npz"))
         assert int(G["iters_f64_stair"]) == want and int(G["iters_f32_stair"]) == want
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The C restatement built with -fsanitize=address,undefined (CPU only; the GPU pool has no sanitizer runs) and
+    driven by oracle/oracle_selftest.c: the reference's example system under every flag combination (6 iterations,
+    SURVEY.md section 8c), ragged small shapes with NaN-poisoned L_0 / R_{N-1} in exact-size buffers, both
+    precisions, 1 and 3 OpenMP threads.  Any out-of-bounds access, signed overflow or misaligned access aborts
+    the binary."""
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", odir, "asan"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(odir, "oracle_selftest_asan")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="3"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "oracle selftest ok" in out.stdout and "FAIL" not in out.stdout
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
