@@ -30,6 +30,9 @@ struct gbdpcg_context {
     // split-path workspace, grown on demand outside capture
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // persistent path: hand-off slots and epoch bases, zero-filled when (re)allocated, grown outside capture
+    void *pws = nullptr;
+    size_t pws_bytes = 0;
     // Buffers replaced by a larger one.  Graphs built earlier (gbdpcg_graph_create_solve_*, or a caller's own
     // capture of gbdpcg_solve_*) hold the OLD pointers in their kernel nodes, so growth never frees: the old
     // buffer stays valid until the handle goes.  Sizes at least double, which bounds the total at 2x the largest.
@@ -117,9 +120,18 @@ template <typename T> bool mappable(uint32_t n)
 template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch)
 {
     const bool fits = fused_fits<T>(h->dev, n, N);
+    const bool persist = persist_knots_per_wg<T>(h->dev, n, N, batch) != 0;
+    if (h->forced == GBDPCG_PATH_PERSISTENT) return persist ? GBDPCG_PATH_PERSISTENT : (fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT);
     if (h->forced == GBDPCG_PATH_FUSED) return fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT;
     if (h->forced == GBDPCG_PATH_SPLIT) return GBDPCG_PATH_SPLIT;
-    if (!fits) return GBDPCG_PATH_SPLIT;
+    // A problem too large for one workgroup: one persistent launch over many CUs when all of its workgroups can be
+    // resident together (measured on config 4, n=36 N=256 fp64: see DESIGN.md), else two launches per iteration.
+    if (!fits) return persist ? GBDPCG_PATH_PERSISTENT : GBDPCG_PATH_SPLIT;
+    // Fits one workgroup but would stream both matrices through ONE CU's share of the fabric every iteration
+    // (43 GB/s measured, below): the persistent launch keeps them in registers and pays ~5.7 us per iteration.
+    if (persist && !resident_shape<T>(n, N) && !(h->symmetric != 0 && resident_sym_shape<T>(n, N)) &&
+        6.0 * n * n * N * sizeof(T) / 43e9 > 6e-6)
+        return GBDPCG_PATH_PERSISTENT;
     // Shapes whose matrices stay on the CU for the whole solve: fused, whatever the batch.  (Symmetric mode 2
     // decides per problem on the device; the path is chosen for the problems that pass.)
     if (resident_shape<T>(n, N)) return GBDPCG_PATH_FUSED;
@@ -167,6 +179,17 @@ gbdpcg_status grow_buffer(gbdpcg_handle_t h, void **buf, size_t *cap, size_t nee
 
 gbdpcg_status ensure_ws(gbdpcg_handle_t h, size_t bytes) { return grow_buffer(h, &h->ws, &h->ws_bytes, bytes); }
 
+// The persistent path's workspace must read zero where it was never written (epoch bases, tags): fill after growth.
+gbdpcg_status ensure_pws(gbdpcg_handle_t h, size_t bytes)
+{
+    if (bytes <= h->pws_bytes) return GBDPCG_OK;
+    gbdpcg_status st = grow_buffer(h, &h->pws, &h->pws_bytes, bytes);
+    if (st != GBDPCG_OK) return st;
+    hipError_t e = hipMemset(h->pws, 0, h->pws_bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e == hipSuccess ? GBDPCG_OK : fail(h, e);
+}
+
 gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
 {
     return grow_buffer(h, reinterpret_cast<void **>(&h->sym_flags), &h->sym_cap, batch);
@@ -182,7 +205,17 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
     DEVICE_SCOPE(h);
-    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_FUSED) {
+    const gbdpcg_path path = pick_path<T>(h, n, N, batch);
+    if (path == GBDPCG_PATH_PERSISTENT) {
+        const size_t need = persist_workspace_bytes<T>(n, N, batch);
+        if (need > h->pws_bytes) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GBDPCG_ERR_ALLOC;
+            gbdpcg_status st = ensure_pws(h, need);
+            if (st != GBDPCG_OK) return st;
+        }
+        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, h->pws, stream));
+    } else if (path == GBDPCG_PATH_FUSED) {
         const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
         if (has_sym && h->symmetric == 2 && given_verdict_stride) {
             // the verdict bytes are already in h->sym_flags, put there on this stream by the stair kernel that just
@@ -376,7 +409,10 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     *out = nullptr;
     if (!shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     DEVICE_SCOPE(h);
-    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
+    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT) {
+        gbdpcg_status st = ensure_pws(h, persist_workspace_bytes<T>(n, N, batch));
+        if (st != GBDPCG_OK) return st;
+    } else if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
     } else if (h->symmetric == 2) {
@@ -497,6 +533,7 @@ gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
     if (!h) return GBDPCG_ERR_INVALID;
     DeviceScope scope(h->dev.device);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->pws) (void)hipFree(h->pws);
     if (h->sym_flags) (void)hipFree(h->sym_flags);
     for (void *old : h->retired) (void)hipFree(old);
     if (h->d_iters) (void)hipFree(h->d_iters);
@@ -528,7 +565,7 @@ const char *gbdpcg_last_hip_error_string(gbdpcg_handle_t h)
 
 gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path)
 {
-    if (!h || (int)path < 0 || (int)path > 2) return GBDPCG_ERR_INVALID;
+    if (!h || (int)path < 0 || (int)path > 3) return GBDPCG_ERR_INVALID;
     h->forced = path;
     return GBDPCG_OK;
 }
@@ -599,11 +636,13 @@ size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n,
 {
     if (!h || !shape_ok(n, N, batch)) return 0;
     if (elem_size == 8) {
-        if (pick_path<double>(h, n, N, batch) == GBDPCG_PATH_FUSED) return 0;
-        return split_workspace_bytes<double>(n, N, batch);
+        const gbdpcg_path p = pick_path<double>(h, n, N, batch);
+        if (p == GBDPCG_PATH_FUSED) return 0;
+        return p == GBDPCG_PATH_PERSISTENT ? persist_workspace_bytes<double>(n, N, batch) : split_workspace_bytes<double>(n, N, batch);
     }
-    if (pick_path<float>(h, n, N, batch) == GBDPCG_PATH_FUSED) return 0;
-    return split_workspace_bytes<float>(n, N, batch);
+    const gbdpcg_path p = pick_path<float>(h, n, N, batch);
+    if (p == GBDPCG_PATH_FUSED) return 0;
+    return p == GBDPCG_PATH_PERSISTENT ? persist_workspace_bytes<float>(n, N, batch) : split_workspace_bytes<float>(n, N, batch);
 }
 
 gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
@@ -613,6 +652,8 @@ gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, 
     // the verdict bytes of the device symmetry check (mode 2) must exist before a capture as well
     gbdpcg_status st = ensure_sym_flags(h, elem_size == 8 ? verdict_bytes<double>(n, N, batch) : verdict_bytes<float>(n, N, batch));
     if (st != GBDPCG_OK) return st;
+    const gbdpcg_path p = elem_size == 8 ? pick_path<double>(h, n, N, batch) : pick_path<float>(h, n, N, batch);
+    if (p == GBDPCG_PATH_PERSISTENT) return ensure_pws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
     return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
 }
 
@@ -777,5 +818,10 @@ gbdpcg_status gbdpcg_csr_to_bt_f64(uint32_t n, uint32_t N, const uint32_t *row_p
 }
 
 const char *gbdpcg_version(void) { return "gbdpcg 0.1 gfx950"; }
+
+#ifdef GBDPCG_PERSIST_STAMPS
+// diagnostic build only (tools/persist_stamps.py): where the persistent path keeps its stamps
+void *gbdpcg_internal_persist_ws(gbdpcg_handle_t h) { return h ? h->pws : nullptr; }
+#endif
 
 }  // extern "C"

@@ -99,6 +99,15 @@ template <typename T>
 hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,
                             const volatile uint32_t *host_done_poll = nullptr);
 
+// ---- pcg_persist.hip : one large problem over many CUs in ONE persistent launch (matrices register-resident,
+// in-kernel all-gather of {partial inner product, boundary knots} twice per iteration)
+// Knots per workgroup the launch would use; 0 = the shape cannot run persistently on this device.
+template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
+template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
+// workspace: persist_workspace_bytes, ZERO-FILLED once when allocated (epoch bases live there), never cleared again
+template <typename T>
+hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s);
+
 // ---- symcheck.hip : flags[b] = 1 iff L_{k+1} == R_k^T bit for bit for every k of problem b
 // and_into: flags[b] &= result instead of flags[b] = result (second matrix of a pair).
 template <typename T>

@@ -1,0 +1,510 @@
+// pcg_persist.hip -- PCG for ONE large problem spread over many CUs inside a single persistent launch.
+//
+// Replaces pcg<T,n,N> (/root/reference/include/pcg.cuh:54-218) for problems whose vectors do not fit one
+// workgroup (BASELINE config 4: n = 36, N = 256, fp64).  The reference gives every knot a block, keeps the
+// knot's block-rows of S and Pinv in shared memory for the whole solve (pcg.cuh:104-110) and crosses the grid
+// four times per iteration with grid.sync() (pcg.cuh:166,178,190,207).  Here:
+//
+//   * a workgroup owns K consecutive knots (K = 1, 2 or 4; 256 threads per knot) and keeps their block-rows
+//     [L|D|R] of S and Pinv in REGISTERS for the whole solve: thread (row, group) holds a contiguous run of
+//     COLS columns of its row of both matrices (n = 36: 7 groups x 16 columns, 64 VGPRs in fp64).  The matrices
+//     are read from HBM once per solve; an iteration touches only LDS and the hand-off words below.
+//   * the iteration is cut at its two inner products, as in the split path, but the cut is an in-kernel
+//     ALL-GATHER instead of a kernel boundary: after a product every workgroup publishes, in one go, its
+//     partial of the inner product AND the two boundary knots of the product vector that its neighbours need
+//     (the residual / direction of a neighbour's halo knot is then updated redundantly, so the two axpy
+//     barriers of the reference disappear).  Every workgroup then sums all partials in the same order -> the same
+//     bits everywhere -> the exit test of pcg.cuh:195 stays uniform, exactly what pcg.cuh:147,167,191 ensure.
+//     Two such round trips per iteration: the inner products of textbook PCG depend on each other.
+//   * hand-off words are data-tagged 8-byte granules {epoch, 32 value bits} written and polled with agent-scope
+//     relaxed atomics (sc1 write-through stores / sc1 loads: MI355X_MICROARCH.md, "Valid forms", R2): the data is
+//     the flag, so there is no fence and no separate flag round trip.  An fp64 value is two granules.  Slots are
+//     double-buffered by epoch parity (a producer can be at most one epoch ahead of any consumer); epochs continue
+//     from a per-problem base kept in the workspace, so nothing has to be cleared between launches and the whole
+//     solve is ONE kernel node in a hipGraph.
+//   * one workgroup per CU at most (grid <= CU count), every spin is bounded: a launch that cannot get all its
+//     workgroups resident gives up and reports max_iter_exit = 2 instead of hanging.
+#include <cstdlib>
+#include <type_traits>
+
+#include "bt_device.hpp"
+#include "internal.hpp"
+
+namespace gbdpcg {
+
+typedef unsigned long long u64;
+
+constexpr uint32_t kPersistCtrl = 16;   // u64 control words per problem (a 128-byte line of their own)
+
+template <typename T> struct Gran;
+template <> struct Gran<float> { static constexpr uint32_t PER = 1; };
+template <> struct Gran<double> { static constexpr uint32_t PER = 2; };
+
+#define GBDPCG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ void gran_store(u64 *slot, uint32_t epoch, float v)
+{
+    __hip_atomic_store(slot, ((u64)epoch << 32) | __builtin_bit_cast(uint32_t, v), GBDPCG_RLX_AGENT);
+}
+__device__ __forceinline__ void gran_store(u64 *slot, uint32_t epoch, double v)
+{
+    const u64 b = __builtin_bit_cast(u64, v);
+    __hip_atomic_store(slot, ((u64)epoch << 32) | (b & 0xffffffffull), GBDPCG_RLX_AGENT);
+    __hip_atomic_store(slot + 1, ((u64)epoch << 32) | (b >> 32), GBDPCG_RLX_AGENT);
+}
+// One value slot = Gran<T>::PER adjacent granules; read with ONE sc1 buffer load (8 bytes for fp32, 16 for fp64: each
+// 8-byte half carries its own tag, so a torn 16-byte read is detected, not consumed).  off = byte offset in the region.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;   // cache-policy bits of the raw buffer builtins on gfx94x/gfx950: bit 4 = sc1
+
+__device__ __forceinline__ bool slot_load(__amdgpu_buffer_rsrc_t region, uint32_t off, uint32_t epoch, float &v)
+{
+    const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(region, (int)off, 0, kAuxSc1);
+    v = __builtin_bit_cast(float, x.x);
+    return x.y == epoch;
+}
+__device__ __forceinline__ bool slot_load(__amdgpu_buffer_rsrc_t region, uint32_t off, uint32_t epoch, double &v)
+{
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(region, (int)off, 0, kAuxSc1);
+    v = __builtin_bit_cast(double, ((u64)x.z << 32) | x.x);
+    return x.y == epoch && x.w == epoch;
+}
+
+// Bytes between the partial-product slots of two workgroups.  A slot of its own 128-byte line keeps 8 producers from
+// writing into one line that every consumer polls.
+#ifndef GBDPCG_PERSIST_PSTRIDE
+#define GBDPCG_PERSIST_PSTRIDE 128
+#endif
+constexpr uint32_t kPartStrideWords = GBDPCG_PERSIST_PSTRIDE / 8;
+#ifndef GBDPCG_PERSIST_SLEEP0
+#define GBDPCG_PERSIST_SLEEP0 0
+#endif
+
+// Workspace of one problem, in u64 words: [ctrl | part[2][N] slots | halo[2][N][2][n] values], sized for one knot
+// per workgroup (the largest workgroup count), whatever K a launch uses.
+template <typename T> __host__ __device__ inline size_t persist_part_words(uint32_t N)
+{
+    return (size_t)2 * N * (kPartStrideWords > Gran<T>::PER ? kPartStrideWords : Gran<T>::PER);
+}
+template <typename T> __host__ __device__ inline size_t persist_words(uint32_t n, uint32_t N)
+{
+    return kPersistCtrl + persist_part_words<T>(N) + (size_t)2 * N * 2 * n * Gran<T>::PER;
+}
+
+// Wave 0 of a workgroup: poll until every partial of this epoch and the two neighbour boundary vectors have
+// arrived (sc1 loads, no fence: the data is the flag), then sum the partials in a fixed order.  Every lane re-reads
+// only the slots it is still missing and sleeps between passes: polling traffic competes with the very stores it is
+// waiting for (measured on config 4: keeping two / three polls in flight per slot made an iteration 19 % / 36 % slower).
+// part_off: byte offset of this epoch parity's partial slots in the region; hl_off / hr_off: byte offsets of the left /
+// right neighbour's boundary vector (negative: no neighbour).  Returns false when the spin bound is hit.
+#ifndef GBDPCG_PERSIST_GAP
+#define GBDPCG_PERSIST_GAP 1
+#endif
+template <typename T, int NCT, uint32_t PJ>
+__device__ __forceinline__ bool persist_sweep_w(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
+                                                uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit, T &total,
+                                                T *yl, T *yr)
+{
+    constexpr uint32_t PER = Gran<T>::PER, PSTRIDE = (kPartStrideWords > PER ? kPartStrideWords : PER) * 8;
+    static_assert(NCT <= 64, "one halo value per lane");
+    T pv[PJ], hl = T(0), hr = T(0);
+    bool have[PJ], have_l = hl_off < 0 || lane >= (uint32_t)NCT, have_r = hr_off < 0 || lane >= (uint32_t)NCT;
+#pragma unroll
+    for (uint32_t j = 0; j < PJ; ++j) {
+        pv[j] = T(0);
+        have[j] = lane + 64 * j >= W;
+    }
+    if (GBDPCG_PERSIST_SLEEP0) __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_SLEEP0);
+    for (uint32_t spins = 0;; ++spins) {
+        bool all = true;
+#pragma unroll
+        for (uint32_t j = 0; j < PJ; ++j) {
+            if (!have[j]) have[j] = slot_load(region, part_off + (lane + 64 * j) * PSTRIDE, epoch, pv[j]);
+            all = all && have[j];
+        }
+        if (!have_l) have_l = slot_load(region, (uint32_t)hl_off + lane * PER * 8, epoch, hl);
+        if (!have_r) have_r = slot_load(region, (uint32_t)hr_off + lane * PER * 8, epoch, hr);
+        if (__all(all && have_l && have_r)) break;
+        if (spins >= spin_limit) return false;
+        __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_GAP);
+    }
+    T s = pv[0];
+#pragma unroll
+    for (uint32_t j = 1; j < PJ; ++j) s += pv[j];
+    total = wave_sum(s);
+    if (lane < (uint32_t)NCT) {
+        yl[lane] = hl;
+        yr[lane] = hr;
+    }
+    return true;
+}
+template <typename T, int NCT>
+__device__ __forceinline__ bool persist_sweep(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
+                                              uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit, T &total,
+                                              T *yl, T *yr)
+{
+    // partial slots per lane: the sums differ between the three forms only in how many zeros they add
+    if (W <= 64) return persist_sweep_w<T, NCT, 1>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    if (W <= 128) return persist_sweep_w<T, NCT, 2>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    return persist_sweep_w<T, NCT, 4>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+}
+
+// acc = sum_i m[i] * (A[i] + coef * B[i]) over this thread's COLS columns, ascending.  The operands come out of LDS
+// in 16-byte pieces, STEP columns per step.  FENCED (three knots per workgroup: 960 threads, 128 VGPRs): the steps are
+// pinned in order, because left alone hipcc hoists all 2 * COLS reads above the first multiply and spills; with fewer
+// threads the hoisting is what we want (one LDS latency per product instead of one per step).
+template <typename T, uint32_t COLS, bool FENCED>
+__device__ __forceinline__ T persist_row_dot(const T (&m)[COLS], const T *A, const T *B, T coef)
+{
+    constexpr uint32_t VW = 16 / sizeof(T), STEP = COLS % 4 == 0 ? 4 : VW;
+    static_assert(COLS % STEP == 0 && STEP % VW == 0, "columns per thread come in whole 16-byte pieces");
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    T acc = T(0);
+#pragma unroll
+    for (uint32_t i0 = 0; i0 < COLS; i0 += STEP) {
+        T av[STEP], bv[STEP];
+#pragma unroll
+        for (uint32_t q = 0; q < STEP / VW; ++q) {
+            const vec_t va = *reinterpret_cast<const vec_t *>(A + i0 + q * VW), vb = *reinterpret_cast<const vec_t *>(B + i0 + q * VW);
+#pragma unroll
+            for (uint32_t e = 0; e < VW; ++e) {
+                av[q * VW + e] = va[e];
+                bv[q * VW + e] = vb[e];
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < STEP; ++j) acc = fma_t(m[i0 + j], fma_t(coef, bv[j], av[j]), acc);
+        if (FENCED) __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
+// Sum over the 8 lanes of an aligned group, in the VALU (DPP quad permutes + half mirror): every lane gets the total.
+template <typename T> __device__ __forceinline__ T group_sum8(T v)
+{
+    v = dpp_add<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm:[2,3,0,1]
+    return dpp_add<0x141>(v);  // row_half_mirror
+}
+
+enum PersistPhase { PP_INIT = 0, PP_PRECOND = 1, PP_DIRECTION = 2 };
+
+// Diagnostic build only (-DGBDPCG_PERSIST_STAMPS): workgroup 1 leaves cycle stamps of the phases of iteration 3 in the
+// unused control words of the workspace (read back by tools/persist_stamps.py).  No stamp exists in the shipped build.
+#ifdef GBDPCG_PERSIST_STAMPS
+#define GBDPCG_STAMP(IDX, COND)                                                                   \
+    if ((COND) && lane == 0) ws[IDX] = __builtin_amdgcn_s_memtime();
+#define GBDPCG_STAMP_RT(IDX, COND)                                                                \
+    if ((COND) && lane == 0) ws[IDX] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GBDPCG_STAMP(IDX, COND)
+#define GBDPCG_STAMP_RT(IDX, COND)
+#endif
+
+// Lane map of one knot: aligned groups of 8 lanes share a row, lane g of the group holds columns [g*COLS, (g+1)*COLS) of
+// that row of S and of Pinv in registers; a wave covers 8 rows, ceil(n/8) waves a knot (n = 36: 5 waves, 14 columns per
+// lane, 56 VGPRs of fp64 matrix data).  The 8 partial sums of a row are folded with three DPP adds, so a product needs
+// no LDS round trip and no barrier of its own.
+template <typename T, int NCT> struct PersistGeom {
+    static constexpr uint32_t n = NCT, G = 8, WPK = (n + 7) / 8, TPK = WPK * 64, VW = 16 / sizeof(T);
+    static constexpr uint32_t COLS = ((3 * n + G - 1) / G + VW - 1) / VW * VW;
+};
+
+template <typename T, int NCT, int K, bool HAS_PINV>
+__global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_kernel(PcgArgs<T> a, u64 *ws_all, uint32_t W,
+                                                                                     uint32_t spin_limit)
+{
+    using Gm = PersistGeom<T, NCT>;
+    constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
+    constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0;   // PUB: the publishing wave
+    constexpr uint32_t WIN = (K + 2) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n;
+    static_assert(3 * n <= G * COLS && THREADS <= 1024, "lane map");
+    static_assert((n * sizeof(T)) % 16 == 0 && (COLS * sizeof(T)) % 16 == 0, "operand runs start on 16-byte boundaries");
+
+    __shared__ __attribute__((aligned(16))) T rwin[2][WINP];
+    __shared__ __attribute__((aligned(16))) T pwin[2][WINP];
+    __shared__ __attribute__((aligned(16))) T uwin[WINP];   // upsilon = S p, window form
+    __shared__ __attribute__((aligned(16))) T twin[WINP];   // r~ = Pinv r, window form
+    __shared__ __attribute__((aligned(16))) T lwin[WINP];   // lambda window of the prologue
+    __shared__ __attribute__((aligned(16))) T lam[OWN];
+    __shared__ T dots[NWAVES];   // per-wave shares of the inner product
+    __shared__ T bc[4];          // [0] coefficient of the next phase, [1] eta, [2] beta of the last direction update
+    __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out), [1] iterations
+
+    const uint32_t N = a.N, len = n * N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t slot = wave / WPK, wv = wave - slot * WPK;
+    const uint32_t g = lane & 7u, row = wv * 8 + (lane >> 3);
+    const bool row_live = row < n;
+    const uint32_t cbase = g * COLS;
+    const uint32_t oi = slot * n + (row_live ? row : 0u);   // this lane's row in the own part of a vector
+
+    // chunk index: blocks b and b + 8 share an XCD (round-robin dispatch), so consecutive chunks -- the ones that
+    // exchange halo knots -- are put on one XCD.  Speed only: the protocol does not depend on placement.
+    const uint32_t prob = blockIdx.x / W, b = blockIdx.x - prob * W;
+    const uint32_t w = (W % 8 == 0) ? (b % 8) * (W / 8) + b / 8 : b;
+    const uint32_t k0 = w * K, k = k0 + slot;
+    const bool knot_live = k < N;
+
+    const size_t mstride = (size_t)3 * n * n * N;
+    const T *S = a.S + prob * mstride;
+    const T *P = HAS_PINV ? a.Pinv + prob * mstride : nullptr;
+    const T *gamma = a.gamma + (size_t)prob * len;
+    T *lambda = a.lambda + (size_t)prob * len;
+
+    u64 *ws = ws_all + (size_t)prob * persist_words<T>(n, N);
+    constexpr uint32_t PSW = kPartStrideWords > PER ? kPartStrideWords : PER;   // u64 words per partial slot
+    u64 *part = ws + kPersistCtrl;                              // [2][N] slots
+    u64 *halo = part + persist_part_words<T>(N);                // [2][N][2][n] values
+    // the same words as a buffer resource for the polling loads (byte offsets from `part`)
+    const __amdgpu_buffer_rsrc_t region = __builtin_amdgcn_make_buffer_rsrc(
+        part, 0, (int)((persist_words<T>(n, N) - kPersistCtrl) * 8), 0x00020000);
+    const uint32_t halo_base = (uint32_t)(persist_part_words<T>(N) * 8);
+    const uint32_t base = (uint32_t)__hip_atomic_load(ws, GBDPCG_RLX_AGENT);   // epochs of this launch continue from here
+
+    // ---- resident matrices: this lane's COLS columns of its row, both matrices -----------------------------------
+    T sreg[COLS], preg[COLS];
+    {
+        const T *Sk = S + (size_t)(knot_live ? k : 0u) * 3 * n * n;
+        const T *Pk = (HAS_PINV ? P : S) + (size_t)(knot_live ? k : 0u) * 3 * n * n;
+        // all 2 * COLS loads first (one memory round trip), the selections afterwards
+        T sraw[COLS], praw[COLS];
+#pragma unroll
+        for (uint32_t i = 0; i < COLS; ++i) {
+            const uint32_t c = cbase + i;
+            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
+            const uint32_t idx = valid ? c * n + row : n * n;   // else an element of D_k: always there
+            sraw[i] = Sk[idx];
+            if (HAS_PINV) praw[i] = Pk[idx];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t i = 0; i < COLS; ++i) {
+            const uint32_t c = cbase + i;
+            // L_0 and R_{N-1} are never used (pcg.cuh:105-106): zero, whatever the storage holds
+            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
+            sreg[i] = valid ? sraw[i] : T(0);
+            if (HAS_PINV) preg[i] = valid ? praw[i] : T(0);
+            else preg[i] = (valid && c == n + row) ? T(1) : T(0);   // d_Pinv == NULL: identity preconditioner
+        }
+    }
+
+    // ---- LDS state ---------------------------------------------------------------------------------------------
+    for (uint32_t i = tid; i < WINP; i += THREADS) {
+        rwin[0][i] = rwin[1][i] = pwin[0][i] = pwin[1][i] = uwin[i] = twin[i] = T(0);
+        const int64_t gi = (int64_t)k0 * n - n + i;   // window element i = vector element gi
+        lwin[i] = (i < WIN && gi >= 0 && gi < (int64_t)len) ? lambda[gi] : T(0);
+    }
+    for (uint32_t i = tid; i < OWN; i += THREADS) lam[i] = (k0 * n + i < len) ? lambda[k0 * n + i] : T(0);
+    if (tid == 0) {
+        bc[0] = bc[1] = bc[2] = T(0);
+        bci[0] = bci[1] = 0u;
+    }
+    __syncthreads();
+
+    uint32_t rc = 0, pc = 0;   // current r / p window
+
+    // One phase: y = M X over the own knots with X = A + coef * B formed on the fly; the row owners (lane 0 of each
+    // group) store y, the new operand window NEW, publish the boundary knots and their share of the inner product; then
+    // wave 0 publishes the workgroup's partial, gathers everybody's and decides what comes next.
+#define GBDPCG_PERSIST_PHASE(PHASE, MREG, A, B, NEW, YWIN, EPOCH, ITER)                                              \
+    {                                                                                                                \
+        const T coef = bc[0];                                                                                        \
+        const uint32_t tag = base + (EPOCH), par = (EPOCH) & 1u;                                                     \
+        const bool stamp_here = w == 1 && wave == 0 && (ITER) == 3;                                                  \
+        const uint32_t sb = PHASE == PP_DIRECTION ? 2u : 8u;                                                         \
+        (void)stamp_here;                                                                                            \
+        (void)sb;                                                                                                    \
+        GBDPCG_STAMP(sb + 0, stamp_here)                                                                             \
+        GBDPCG_STAMP_RT(PHASE == PP_DIRECTION ? 14u : 15u, stamp_here)                                               \
+        /* operands of the row owners and the two halo knots of the new window first: their LDS round trips run   \
+           under the product's */                                                                                    \
+        const T own_a = (A)[n + oi], own_b = (B)[n + oi], own_p = pwin[pc][n + oi], own_l = lam[oi];                  \
+        if ((NEW) != nullptr) {                                                                                      \
+            for (uint32_t i = tid; i < 2 * n; i += THREADS) {                                                        \
+                const uint32_t j = i < n ? i : OWN + i;                                                              \
+                (NEW)[j] = fma_t(coef, (B)[j], (A)[j]);                                                              \
+            }                                                                                                        \
+        }                                                                                                            \
+        T y = persist_row_dot<T, COLS, (THREADS > 768)>(MREG, (A) + slot * n + cbase, (B) + slot * n + cbase, coef);   \
+        GBDPCG_STAMP(1, stamp_here && PHASE == PP_DIRECTION)                                                         \
+        y = group_sum8(y);                                                                                           \
+        T d = T(0);                                                                                                  \
+        if (g == 0 && row_live) {                                                                                    \
+            const T xo = fma_t(coef, own_b, own_a);   /* this row of the operand */                                  \
+            if (PHASE == PP_INIT) y = (knot_live ? gamma[k * n + row] : T(0)) - y;   /* r = gamma - S lambda */      \
+            (YWIN)[n + oi] = y;                                                                                      \
+            if ((NEW) != nullptr) (NEW)[n + oi] = xo;                                                                \
+            if (PHASE == PP_PRECOND && (NEW) != nullptr)   /* lambda += alpha p   (pcg.cuh:172-174); coef = -alpha */ \
+                lam[oi] = fma_t(-coef, own_p, own_l);                                                                \
+            if (PHASE != PP_INIT) d = xo * y;                                                                        \
+        }                                                                                                            \
+        d = wave_sum(d);                                                                                             \
+        if (lane == 0) dots[wave] = d;                                                                               \
+        GBDPCG_STAMP(7, stamp_here && PHASE == PP_DIRECTION)                                                         \
+        GBDPCG_STAMP(13, stamp_here && PHASE == PP_DIRECTION)                                                        \
+        __syncthreads();                                                                                             \
+        GBDPCG_STAMP(sb + 1, stamp_here)                                                                             \
+        /* No global store is issued before the barrier above (it would make every wave wait for the write-through  \
+           acknowledgement), and none by the polling wave (its loads would queue behind them): wave PUB publishes. */  \
+        if (wave == PUB) {                                                                                           \
+            u64 *my_halo = halo + (((size_t)par * N + w) * 2) * n * PER;                                             \
+            for (uint32_t i = lane; i < 2 * n; i += 64) {   /* first knot -> left neighbour, last knot -> right */     \
+                const uint32_t src = i < n ? n + i : n + (K - 1) * n + (i - n);                                       \
+                gran_store(my_halo + (size_t)i * PER, tag, (YWIN)[src]);                                             \
+            }                                                                                                        \
+            T dot = dots[0];                                                                                         \
+            _Pragma("unroll") for (uint32_t q = 1; q < NWAVES; ++q) dot += dots[q];                                 \
+            if (lane == 0) gran_store(part + ((size_t)par * N + w) * PSW, tag, dot);                                 \
+        }                                                                                                            \
+        if (wave == 0) {                                                                                             \
+            GBDPCG_STAMP(sb + 2, stamp_here)                                                                         \
+            T total;                                                                                                 \
+            const bool ok = persist_sweep<T, NCT>(                                                                   \
+                region, par * N * PSW * 8u,                                                                          \
+                w > 0 ? (int)(halo_base + ((par * N + (w - 1)) * 2 + 1) * n * PER * 8u) : -1,                        \
+                w + 1 < W ? (int)(halo_base + ((par * N + (w + 1)) * 2) * n * PER * 8u) : -1, W, tag, lane,          \
+                spin_limit, total, (YWIN), (YWIN) + n + OWN);                                                        \
+            GBDPCG_STAMP(sb + 3, stamp_here)                                                                         \
+            if (lane == 0) {                                                                                         \
+                if (!ok) {                                                                                           \
+                    bci[0] = 2u;                                                                                     \
+                } else if (PHASE == PP_INIT) {                                                                       \
+                    bc[0] = T(0);                                                                                    \
+                } else if (PHASE == PP_DIRECTION) {        /* alpha = eta / (p . upsilon)      (pcg.cuh:169) */      \
+                    bc[0] = -(bc[1] / total);                                                                        \
+                } else if ((ITER) < 0) {                    /* prologue: eta = r . r~, p = r~  (pcg.cuh:139-149) */   \
+                    bc[1] = total;                                                                                   \
+                    bc[0] = bc[2] = T(0);                                                                            \
+                } else if (fabs(total) < a.tol) {           /* pcg.cuh:195 */                                         \
+                    bci[0] = 1u;                                                                                     \
+                    bci[1] = (uint32_t)(ITER) + 1u;                                                                  \
+                } else {                                    /* beta = eta' / eta ; eta = eta'  (pcg.cuh:199-202) */   \
+                    bc[0] = bc[2] = total / bc[1];                                                                   \
+                    bc[1] = total;                                                                                   \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+        GBDPCG_STAMP(sb + 4, stamp_here)                                                                             \
+    }
+
+    T *const none = nullptr;
+    // r = gamma - S lambda (pcg.cuh:118-126); the boundary knots of r travel with epoch 1
+    GBDPCG_PERSIST_PHASE(PP_INIT, sreg, lwin, lwin, none, rwin[0], 1u, -1)
+    // r~ = Pinv r ; eta = r . r~ (pcg.cuh:130-149)
+    if (bci[0] == 0u) GBDPCG_PERSIST_PHASE(PP_PRECOND, preg, rwin[0], rwin[0], none, twin, 2u, -1)
+
+    uint32_t iter = 0;
+    bool ran_out = true;
+    for (; iter < a.max_iter && bci[0] == 0u; ++iter) {   // pcg.cuh:154
+        // p = r~ + beta p ; upsilon = S p ; alpha = eta / (p . upsilon)   (pcg.cuh:203-206,156-169)
+        GBDPCG_PERSIST_PHASE(PP_DIRECTION, sreg, twin, pwin[pc], pwin[pc ^ 1], uwin, 3u + 2u * iter, (int)iter)
+        pc ^= 1u;
+        if (bci[0] != 0u) break;
+        // lambda += alpha p ; r -= alpha upsilon ; r~ = Pinv r ; eta' = r . r~   (pcg.cuh:172-193)
+        GBDPCG_PERSIST_PHASE(PP_PRECOND, preg, rwin[rc], uwin, rwin[rc ^ 1], twin, 4u + 2u * iter, (int)iter)
+        rc ^= 1u;
+        if (bci[0] == 1u) {
+            ran_out = false;
+            break;
+        }
+    }
+#undef GBDPCG_PERSIST_PHASE
+
+    // ---- outputs (pcg.cuh:212,215) --------------------------------------------------------------------------------
+    const bool failed = bci[0] == 2u;
+    const T beta = ran_out ? bc[2] : T(0);   // the last iteration did not break: it still ran p = r~ + beta p
+    for (uint32_t i = tid; i < OWN; i += THREADS) {
+        const uint32_t gi = k0 * n + i;
+        if (gi < len) {
+            lambda[gi] = lam[i];
+            if (a.r) a.r[(size_t)prob * len + gi] = rwin[rc][n + i];
+            if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pwin[pc][n + i], twin[n + i]) : pwin[pc][n + i];
+        }
+    }
+    if (w == 0 && tid == 0) {
+        a.iters[prob] = failed ? 0xffffffffu : (ran_out ? a.max_iter : bci[1]);
+        if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (ran_out ? 1 : 0);
+        // every workgroup read `base` before its first publish, and this workgroup has seen all of those
+        __hip_atomic_store(ws, (u64)(base + 2u * a.max_iter + 8u), GBDPCG_RLX_AGENT);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+
+#define GBDPCG_PERSIST_N(X) X(36)
+
+template <typename T> static bool persist_has_kernel(uint32_t n)
+{
+#define GBDPCG_CASE(NN) \
+    if (n == NN) return true;
+    GBDPCG_PERSIST_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
+    return false;
+}
+
+// Knots per workgroup for this launch (0: the shape cannot run persistently): every workgroup must be resident at
+// once, one per CU.
+template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch)
+{
+    static const bool off = getenv("GBDPCG_NO_PERSIST") != nullptr;   // tuning runs only
+    if (off || !persist_has_kernel<T>(n)) return 0;
+    static const int forced = [] {
+        const char *e = getenv("GBDPCG_PERSIST_K");   // tuning runs only
+        return e ? atoi(e) : 0;
+    }();
+    // two knots per workgroup measured fastest on config 4 (5.7 us per iteration; 6.2 with three, 6.9 with one)
+    for (uint32_t K : {2u, 3u, 1u}) {
+        if (forced && (uint32_t)forced != K) continue;
+        if ((uint64_t)((N + K - 1) / K) * batch <= (uint64_t)dev.num_cus && (N + K - 1) / K <= 256) return K;
+    }
+    return 0;
+}
+
+template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch)
+{
+    return persist_words<T>(n, N) * sizeof(u64) * batch;
+}
+
+template <typename T, int NCT, int K>
+static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStream_t s)
+{
+    const uint32_t W = (a.N + K - 1) / K;
+    // ~1 us per failed pass: a launch whose workgroups are not all resident gives up after about two seconds
+    const uint32_t spin_limit = 1u << 21;
+    if (a.Pinv)
+        hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, true>), dim3(W * a.batch), dim3(K * PersistGeom<T, NCT>::TPK), 0,
+                           s, a, reinterpret_cast<u64 *>(workspace), W, spin_limit);
+    else
+        hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, false>), dim3(W * a.batch), dim3(K * PersistGeom<T, NCT>::TPK), 0,
+                           s, a, reinterpret_cast<u64 *>(workspace), W, spin_limit);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s)
+{
+    const uint32_t K = persist_knots_per_wg<T>(dev, a.n, a.N, a.batch);
+    if (K == 0 || workspace == nullptr) return hipErrorInvalidValue;
+#define GBDPCG_CASE(NN)                                                       \
+    if (a.n == NN) {                                                          \
+        if (K == 1) return launch_persist_k<T, NN, 1>(a, workspace, s);       \
+        if (K == 2) return launch_persist_k<T, NN, 2>(a, workspace, s);       \
+        return launch_persist_k<T, NN, 3>(a, workspace, s);                   \
+    }
+    GBDPCG_PERSIST_N(GBDPCG_CASE)
+#undef GBDPCG_CASE
+    return hipErrorInvalidValue;
+}
+
+template uint32_t persist_knots_per_wg<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
+template uint32_t persist_knots_per_wg<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
+template size_t persist_workspace_bytes<float>(uint32_t, uint32_t, uint32_t);
+template size_t persist_workspace_bytes<double>(uint32_t, uint32_t, uint32_t);
+template hipError_t launch_pcg_persist<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t);
+template hipError_t launch_pcg_persist<double>(const DeviceInfo &, const PcgArgs<double> &, void *, hipStream_t);
+
+}  // namespace gbdpcg

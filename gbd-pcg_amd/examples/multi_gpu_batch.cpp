@@ -117,7 +117,7 @@ void device_thread(Shared &sh, int dev, Report &rep)
 
     gbdpcg_graph_t graph = nullptr;
     PCG_OK(gbdpcg_graph_create_form_pinv_solve_f32(h, n, N, cnt, dS, dP, GBDPCG_PINV_STAIR, dg, dl, nullptr, nullptr, 1e-6f,
-                                                   25, d_iters, d_flags, &graph));
+                                                   100, d_iters, d_flags, &graph));
     // warm-up replay, then all devices start their timed replays together
     HIP_OK(hipMemsetAsync(dl, 0, vsz * cnt * 4, stream));
     PCG_OK(gbdpcg_graph_launch(graph, stream));

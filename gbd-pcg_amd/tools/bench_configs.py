@@ -62,12 +62,12 @@ def main():
         it = torch.zeros(B, dtype=torch.int32, device="cuda")
         fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
         mat = (3 * N - 2) * n * n * es
-        for path, pname in ((binding.PATH_FUSED, "fused"), (binding.PATH_SPLIT, "split")):
+        for path, pname in ((binding.PATH_FUSED, "fused"), (binding.PATH_SPLIT, "split"), (binding.PATH_PERSISTENT, "persist")):
             solver.set_path(path)
             chosen = solver.choose_path(es, n, N, B)
             if chosen != path:
                 continue  # forced path does not fit this shape
-            for tol, iters, tag in ((0.0, 25, "fixed25"), (1e-6, 25, "tol1e-6")):
+            for tol, iters, tag in ((0.0, 5, "fixed5"), (0.0, 25, "fixed25"), (1e-6, 25, "tol1e-6")):
                 graph = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, tol, iters, it, fl)
 
                 def step():

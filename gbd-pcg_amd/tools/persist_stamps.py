@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where one phase of the persistent kernel (csrc/pcg_persist.hip) spends its time: cycle stamps left by workgroup 1 in
+iteration 3 of a config-4 solve, read from the diagnostic build of the library.
+
+    make -C gbd-pcg_amd/csrc variant NAME=stamps EXTRA=-DGBDPCG_PERSIST_STAMPS
+    GBDPCG_LIB=gbd-pcg_amd/csrc/variants/libgbdpcg_stamps.so [GBDPCG_PERSIST_K=2] python gbd-pcg_amd/tools/persist_stamps.py
+"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from gbd_pcg_amd import binding, synth  # noqa: E402
+
+
+def main():
+    n, N = 36, 256
+    s = binding.Solver(0)
+    s.set_path(binding.PATH_PERSISTENT)
+    g = synth.gen_torch_seeded(n, N, 0, 1, "cuda", torch.float64, seed=1234)
+    S, gamma = g["S"], g["gamma"]
+    P = s.form_pinv(n, N, 1, S, binding.PINV_STAIR)
+    lam = torch.zeros_like(gamma)
+    rows = []
+    for rep in range(12):
+        lam.zero_()
+        s.solve(n, N, 1, S, P, gamma, lam, tol=0.0, max_iter=8)
+        torch.cuda.synchronize()
+        fn = s.lib.gbdpcg_internal_persist_ws
+        fn.restype = ctypes.c_void_p
+        ptr = fn(s.h)
+        host = (ctypes.c_uint64 * 16)()
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(host, ctypes.c_void_p(ptr), 128, 2) == 0
+        rows.append(list(host))
+    for tag, b in (("direction (S p)", 2), ("precond (Pinv r)", 8)):
+        print(tag, ": cycles from phase start to [product+barrier, reduce+publish, sweep done, barrier]")
+        for r in rows[2:]:
+            t = r[b:b + 5]
+            print("   ", [int(x - t[0]) for x in t[1:]])
+    print("direction phase, wave 0: cycles from phase start to [row dot done, owner writes + wave sum done, at barrier, past barrier]")
+    for r in rows[2:]:
+        print("   ", [int(r[i] - r[2]) for i in (1, 7, 13, 3)])
+    # shader clock vs 100 MHz real-time clock between the two phase starts
+    for r in rows[2:5]:
+        print("  phase-to-phase: %d cycles, %d x 10 ns" % (r[8] - r[2], r[15] - r[14]))
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,14 @@ typedef struct gbdpcg_graph *gbdpcg_graph_t;
 typedef enum gbdpcg_path {
     GBDPCG_PATH_AUTO = 0,
     GBDPCG_PATH_FUSED = 1, /* one workgroup per problem, vectors LDS-resident, one launch per solve */
-    GBDPCG_PATH_SPLIT = 2  /* many workgroups per problem, two launches per iteration, vectors in L2/HBM */
+    GBDPCG_PATH_SPLIT = 2, /* many workgroups per problem, two launches per iteration, vectors in L2/HBM */
+    GBDPCG_PATH_PERSISTENT = 3 /* one large problem over many CUs in ONE launch: block-rows register-resident for the
+                                  whole solve (the reference's layout, pcg.cuh:104-110), two in-kernel all-gathers of
+                                  {partial inner product, boundary knots} per iteration instead of 4 grid.sync().  Needs
+                                  every workgroup resident at once (ceil(N/K) * batch <= CU count, K <= 4): do not run
+                                  other kernels on the device concurrently.  A launch that cannot get its workgroups
+                                  resident gives up after a bounded spin and reports d_max_iter_exit = 2,
+                                  d_iters = 0xffffffff (result invalid; use GBDPCG_PATH_SPLIT for such callers). */
 } gbdpcg_path;
 
 /* Preconditioners gbdpcg_form_pinv can build from S. */

@@ -252,10 +252,14 @@ def test_ragged_convergence_in_one_batch(solver, orc, path):
 
 
 def test_auto_path_choice(solver):
-    """BASELINE configs: 2 and 3 run fused (vectors fit one workgroup's LDS), 4 must run split."""
+    """BASELINE configs: 2 and 3 run fused (vectors fit one workgroup's LDS); 4 is spread over many CUs -- as ONE
+    persistent launch when all its workgroups can be resident (one problem, or two), else two launches per iteration."""
     assert solver.choose_path(4, 14, 64, 1) == binding.PATH_FUSED
     assert solver.choose_path(4, 14, 128, 1024) == binding.PATH_FUSED
-    assert solver.choose_path(8, 36, 256, 1) == binding.PATH_SPLIT
+    assert solver.choose_path(8, 36, 256, 1) == binding.PATH_PERSISTENT
+    assert solver.choose_path(8, 36, 256, 2) == binding.PATH_PERSISTENT
+    assert solver.choose_path(8, 36, 256, 16) == binding.PATH_SPLIT
+    assert solver.choose_path(8, 36, 64, 1) == binding.PATH_PERSISTENT    # fits one workgroup, but would stream 2 MB per iteration through one CU
 
 
 def test_blocking_and_host_overloads(solver, orc, golden_dir):

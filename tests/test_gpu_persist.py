@@ -1,0 +1,124 @@
+"""The persistent single-launch path (csrc/pcg_persist.hip; BASELINE config 4: n = 36, N = 256, fp64, one problem)
+against the CPU oracle, through the C ABI.  Tolerances as in test_gpu_parity.py: fp64 1e-10, fp32 1e-6 norm-wise,
+equal iteration counts."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from gbd_pcg_amd import binding, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+P = binding.PATH_PERSISTENT
+
+
+@pytest.fixture(scope="module")
+def solver():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    s = binding.Solver(0)
+    yield s
+    s.close()
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run(solver, n, N, B, S, Pinv, gamma, lam0=None, tol=1e-6, max_iter=100):
+    solver.set_path(P)
+    try:
+        es = S.dtype.itemsize
+        assert solver.choose_path(es, n, N, B) == P, "shape not eligible for the persistent path"
+        dS, dP, dg = dev(S), dev(Pinv), dev(gamma)
+        lam = torch.zeros_like(dg) if lam0 is None else dev(lam0)
+        r, p = torch.full_like(dg, float("nan")), torch.full_like(dg, float("nan"))
+        it, fl = solver.solve(n, N, B, dS, dP, dg, lam, r, p, tol=tol, max_iter=max_iter)
+        torch.cuda.synchronize()
+    finally:
+        solver.set_path(binding.PATH_AUTO)
+    return dict(lambda_=lam.cpu().numpy().reshape(B, -1), r=r.cpu().numpy().reshape(B, -1),
+                p=p.cpu().numpy().reshape(B, -1), iters=it.cpu().numpy().astype(np.int64),
+                flag=fl.cpu().numpy().astype(np.int64))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(256, 1), (255, 1), (129, 1), (100, 2), (37, 3), (5, 2), (3, 1), (2, 1), (1, 2)])
+def test_persistent_vs_oracle(solver, orc, dtype, N, B):
+    n = 36
+    d = synth.gen_numpy(n, N, seed=300 + N, batch=B, dtype=dtype)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"])
+    assert np.array_equal(out["iters"], ob["iters"].astype(np.int64)), (out["iters"], ob["iters"])
+    assert not out["flag"].any()
+    tol = 1e-10 if dtype == np.float64 else 1e-6
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol
+        scale = np.abs(d["gamma"][b]).max()
+        assert np.abs(out["r"][b] - ob["r"].reshape(B, -1)[b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
+        assert np.abs(out["p"][b] - ob["p"][b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_persistent_config4_against_golden(solver, golden_dir, dtype):
+    """BASELINE config 4 (n = 36, N = 256): the committed fp64 golden vector (10 iterations with the stair
+    preconditioner, 30 with the identity -- SURVEY.md section 8c)."""
+    import os
+    G = np.load(os.path.join(golden_dir, "gen_36x256.npz"))
+    n, N = 36, 256
+    d = synth.gen_numpy(n, N, seed=1234, batch=1, dtype=np.float64)
+    S, Pi, g = d["S"].astype(dtype), d["Pinv"].astype(dtype), d["gamma"].astype(dtype)
+    out = run(solver, n, N, 1, S, Pi, g, max_iter=25)
+    assert out["iters"][0] == int(G["iters_f64_stair"]) == 10
+    assert relerr(out["lambda_"][0], G["lambda_f64_stair"]) < (1e-10 if dtype == np.float64 else 2e-6)
+    out = run(solver, n, N, 1, S, None, g, max_iter=100)      # identity preconditioner (d_Pinv == NULL)
+    assert out["iters"][0] == int(G["iters_f64_ident"]) and relerr(out["lambda_"][0], G["lambda_f64_ident"]) < (1e-10 if dtype == np.float64 else 2e-5)
+
+
+@pytest.mark.parametrize("tol,max_iter", [(1e-6, 0), (1e-6, 1), (1e30, 5), (0.0, 2), (0.0, 7)])
+def test_persistent_iteration_edges(solver, orc, tol, max_iter):
+    """max_iter = 0 (only r, p = Pinv r are produced), exit on the first test, and fixed iteration counts: lambda, r, p,
+    iters and the max-iter flag all follow pcg.cuh:154-212."""
+    n, N, B = 36, 70, 2
+    d = synth.gen_numpy(n, N, seed=77, batch=B, dtype=np.float64)
+    lam0 = np.stack([synth.normals(5 + b, 0, n * N) for b in range(B)]) * 0.1
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], lambda0=lam0, tol=tol, max_iter=max_iter)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], lam0=lam0, tol=tol, max_iter=max_iter)
+    assert np.array_equal(out["iters"], ob["iters"].astype(np.int64))
+    assert np.array_equal(out["flag"], ob["max_iter_exit"].astype(np.int64))
+    scale = np.abs(d["gamma"]).max()
+    for key in ("lambda_", "r", "p"):
+        assert np.abs(out[key] - ob[key]).max() < 1e-10 * max(scale, np.abs(ob[key]).max()), key
+
+
+def test_persistent_replays_need_no_clearing(solver, orc):
+    """Epochs continue from a base kept in the workspace: back-to-back solves, a graph replayed many times and a solve
+    with a different max_iter in between all give the same answer (nothing is cleared between launches)."""
+    n, N = 36, 256
+    d = synth.gen_numpy(n, N, seed=1234, batch=1, dtype=np.float64)
+    ob = orc.pcg_batch(n, N, 1, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=25)
+    first = run(solver, n, N, 1, d["S"], d["Pinv"], d["gamma"], max_iter=25)
+    assert first["iters"][0] == ob["iters"][0]
+    run(solver, n, N, 1, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=3)
+    solver.set_path(P)
+    try:
+        dS, dP, dg = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+        lam = torch.zeros_like(dg)
+        r, p = torch.empty_like(dg), torch.empty_like(dg)
+        it = torch.zeros(1, dtype=torch.int32, device="cuda")
+        fl = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        gr = solver.graph_solve(n, N, 1, dS, dP, dg, lam, r, p, 1e-6, 25, it, fl)
+        for _ in range(40):
+            lam.zero_()
+            gr.launch()
+        torch.cuda.synchronize()
+        gr.close()
+    finally:
+        solver.set_path(binding.PATH_AUTO)
+    assert int(it[0]) == ob["iters"][0] and int(fl[0]) == 0
+    assert np.array_equal(lam.cpu().numpy().reshape(1, -1), first["lambda_"])   # bit-identical run to run
