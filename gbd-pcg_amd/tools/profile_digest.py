@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<round>/ (written by profile_round.sh on the GPU box) -> the files committed under profiles/:
+
+    python gbd-pcg_amd/tools/profile_digest.py r02
+
+  profiles/<round>_bench.jsonl                 the bench line of that run (appended)
+  profiles/<round>_bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of `bench.py --no-configs` (this library's
+                                               kernels; config 3 dispatches only); ..._with_configs.csv: the default command
+  profiles/<round>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE per launch (pmc_traffic.py)
+  profiles/<round>_pmc_sq.json                 SQ counters per launch + derived VALU-issue utilisation and LDS
+                                               bank-conflict share (read by bench.py into roofline.valu_issue)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SIMDS = 256 * 4   # MI355X: 256 CUs x 4 SIMDs
+
+
+def counters(root):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        per = collections.defaultdict(float)
+        names = {}
+        for row in csv.DictReader(open(f)):
+            per[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
+            names[row["Dispatch_Id"]] = row["Kernel_Name"]
+        for (d, c), v in per.items():
+            acc[names[d]][c].append(v)
+    return acc
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
+    dst = os.path.join(ROOT, "profiles")
+    line = [ln for ln in open(os.path.join(src, "bench.json")) if ln.startswith("{")][-1]
+    with open(os.path.join(dst, f"{rnd}_bench.jsonl"), "a") as f:
+        f.write(line if line.endswith("\n") else line + "\n")
+    # kernel stats
+    for sub, tag in (("stats", "bench_kernel_stats"), ("stats_configs", "bench_kernel_stats_with_configs")):
+        stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if stats:
+            rows = list(csv.reader(open(stats[0])))
+            keep = [rows[0]] + [r for r in rows[1:] if "gbdpcg" in r[0]]
+            with open(os.path.join(dst, f"{rnd}_{tag}.csv"), "w", newline="") as f:
+                csv.writer(f).writerows(keep)
+    # traffic
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "gbd-pcg_amd", "tools", "pmc_traffic.py"),
+                           os.path.join(src, "fetch"), os.path.join(src, "write"), os.path.join(src, "cal"),
+                           os.path.join(dst, f"{rnd}_pmc_traffic.json")], stdout=subprocess.DEVNULL)
+    # SQ counters
+    out = {"_how": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU "
+                   "SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE on `bench.py --steps 3 --warmup 1` "
+                   "(config 3), one MI355X; mean per dispatch over the long (fixed-25-iteration) dispatches of each kernel. "
+                   "valu_issue_utilisation = SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the "
+                   "kernel's SIMD-cycles in which a vector instruction of a single wave could have been issued (one wave issues a "
+                   "VALU instruction every 4 cycles, MI355X_MICROARCH.md); lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / "
+                   "SQ_LDS_IDX_ACTIVE.  SQ cycle counters are in units of 4 cycles.",
+           "kernels": {}}
+    for name, cs in counters(os.path.join(src, "sq")).items():
+        if "gbdpcg" not in name:
+            continue
+        rec = {}
+        ref = cs.get("SQ_WAVE_CYCLES", [0])
+        big = max(ref) if ref else 0
+        for c, v in cs.items():
+            sel = [x for x, r in zip(v, ref)] if len(v) != len(ref) else [x for x, r in zip(v, ref) if r > 0.5 * big]
+            sel = sel or v
+            rec[c] = sum(sel) / len(sel)
+        rec["dispatches"] = len([r for r in ref if r > 0.5 * big])
+        if rec.get("GRBM_GUI_ACTIVE"):
+            cyc = rec["GRBM_GUI_ACTIVE"] / 8.0
+            rec["kernel_cycles"] = cyc
+            rec["valu_issue_utilisation"] = rec.get("SQ_INSTS_VALU", 0.0) * 4.0 / (cyc * SIMDS)
+        if rec.get("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_bank_conflict_share"] = rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / rec["SQ_LDS_IDX_ACTIVE"]
+        if rec.get("SQ_WAVE_CYCLES"):
+            rec["wait_any_share"] = rec.get("SQ_WAIT_ANY", 0.0) / rec["SQ_WAVE_CYCLES"]
+        short = name.split("(")[0].replace("void gbdpcg::", "").replace(" ", "")
+        out["kernels"][short] = rec
+    json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_sq.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(src, "bw_probe.txt")):
+        open(os.path.join(dst, f"{rnd}_bw_probe.txt"), "w").write(open(os.path.join(src, "bw_probe.txt")).read())
+    print("digested", src, "->", dst)
+
+
+if __name__ == "__main__":
+    main()

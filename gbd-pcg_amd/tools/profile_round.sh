@@ -1,0 +1,31 @@
+#!/bin/bash
+# Everything profiles/rNN_* is derived from, in one GPU-box call (run from the repo root):
+#   bash gbd-pcg_amd/tools/profile_round.sh r02
+# rocprofv3 passes of bench.py (kernel stats; FETCH_SIZE, WRITE_SIZE and SQ counters in separate --pmc passes, each with
+# --kernel-trace only) and of the bandwidth probe that calibrates FETCH_SIZE on reads of known size.  Raw output goes to
+# gpurun_out/prof_<round>/ ; gbd-pcg_amd/tools/profile_digest.py turns it into the files committed under profiles/.
+set -o pipefail
+R=${1:-r02}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/prof_$R
+rm -rf "$OUT"; mkdir -p "$OUT"
+[ -x gbd-pcg_amd/tools/bw_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 gbd-pcg_amd/tools/bw_probe.hip -o gbd-pcg_amd/tools/bw_probe || exit 1
+cd /tmp && export TMPDIR=/tmp
+B="$ROOT/bench.py"
+echo "[1/6] bench line"
+python3 $B > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+echo "[2/6] kernel stats (config 3 only: the dispatches roofline.kernel_ms is measured on; then with the configs block)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B --no-cpu-baseline --no-configs > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 $B --no-cpu-baseline > $OUT/stats_configs.log 2>&1 || { tail -5 $OUT/stats_configs.log; exit 1; }
+echo "[3/6] FETCH_SIZE"
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
+echo "[4/6] WRITE_SIZE"
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
+echo "[5/6] SQ counters"
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+    -d $OUT/sq -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/sq.log 2>&1 || { tail -5 $OUT/sq.log; exit 1; }
+echo "[6/6] FETCH_SIZE calibration (bw_probe)"
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/cal -- $ROOT/gbd-pcg_amd/tools/bw_probe > $OUT/bw_probe.txt 2> $OUT/cal.log || { tail -5 $OUT/cal.log; exit 1; }
+# keep what the digest needs, drop the bulky traces
+find $OUT -name "*.db" -delete 2>/dev/null
+du -sh $OUT
