@@ -21,7 +21,9 @@
 // chunk still reads in the same launch are double-buffered by iteration parity.  A per-problem
 // `done` word turns the launches after convergence into no-ops, which keeps the launch sequence
 // static and hipGraph-capturable.
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 
 #include "bt_device.hpp"
 #include "internal.hpp"
@@ -404,8 +406,16 @@ static hipError_t launch_split_v(const DeviceInfo &dev, const PcgArgs<T> &a, voi
         if (poll) {
             // ... and never run more than kAhead iterations ahead of the device, or everything is enqueued
             // long before the first convergence report arrives (poll[1] = last iteration the device started)
+            // The wait is bounded in TIME (a launch pair takes ~12 us; 2 ms without progress means the stream is stuck
+            // behind other work, and then running ahead is harmless) and gives the core away between looks.
             constexpr uint32_t kAhead = 3;
-            for (uint32_t spins = 0; it >= kAhead && poll[1] + kAhead < it + 1 && poll[0] < a.batch && spins < (1u << 22); ++spins) {
+            if (it >= kAhead) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint32_t looks = 0; poll[1] + kAhead < it + 1 && poll[0] < a.batch; ++looks) {
+                    if (looks < 64) continue;   // the device is usually one launch behind: a few hundred ns
+                    std::this_thread::yield();
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                }
             }
             if (poll[0] >= a.batch) break;
         }

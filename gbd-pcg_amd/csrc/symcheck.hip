@@ -5,10 +5,13 @@
 
 namespace gbdpcg {
 
-// Plain kernels instead of hipMemsetAsync: memset nodes of a hipGraph that is replayed back to back were
-// observed to write garbage patterns on ROCm 7.2 (several replays in flight on the legacy stream: the
-// flags then read 0 / random and every problem silently took the general path); kernel nodes carry
-// their arguments with the graph.
+// Plain kernels instead of hipMemsetAsync.  In round 1 a solve graph whose flags were initialised by a memset node
+// was seen to take the general kernel for every problem when replayed back to back (flags read 0 / garbage) and the
+// nodes were replaced by these kernels.  Round 2 could not reproduce it in any of three forms -- a stand-alone HIP
+// program (tools/memset_node_probe.cpp), this library rebuilt with memset nodes (-DGBDPCG_FILL_WITH_MEMSET,
+// tools/memset_variant_probe.py) and the pre-fix tree itself -- so neither a runtime defect nor a captured-argument
+// bug (hipMemsetAsync takes pointer, value and size by value) is established; DESIGN.md section 3 has the record.  The
+// kernels stay: they cost the same, and the default one-launch check needs no initialisation at all.
 __global__ void fill_bytes_kernel(uint8_t *p, uint8_t v, size_t count)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -19,17 +22,26 @@ __global__ void fill_words_kernel(uint32_t *p, uint32_t v, size_t count)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) p[i] = v;
 }
+// -DGBDPCG_FILL_WITH_MEMSET (diagnostic variant only, tools/memset_variant_probe.py): the round-1 form, memset nodes.
 hipError_t launch_fill_bytes(uint8_t *p, uint8_t v, size_t count, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
+#ifdef GBDPCG_FILL_WITH_MEMSET
+    return hipMemsetAsync(p, v, count, s);
+#else
     hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, v, count);
     return hipGetLastError();
+#endif
 }
 hipError_t launch_fill_words(uint32_t *p, uint32_t v, size_t count, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
+#ifdef GBDPCG_FILL_WITH_MEMSET
+    return v == 0 ? hipMemsetAsync(p, 0, count * sizeof(uint32_t), s) : hipMemsetD32Async((hipDeviceptr_t)p, (int)v, count, s);
+#else
     hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, v, count);
     return hipGetLastError();
+#endif
 }
 
 __device__ __forceinline__ uint32_t bits_of(float v) { return __builtin_bit_cast(uint32_t, v); }

@@ -502,7 +502,14 @@ def test_symmetric_resident_kernel_ill_conditioned(solver, orc):
     o32 = orc.pcg_batch(n, N, B, S32, Ph, g32, tol=1e-6, max_iter=300)
     out = gpu_solve(solver, n, N, B, S32, Ph, g32, tol=1e-6, max_iter=300, path=binding.PATH_FUSED)
     assert not out["max_iter_exit"].any()
-    assert np.abs(out["iters"].astype(np.int64) - o32["iters"].astype(np.int64)).max() <= 1
+    # Why no equality here: at kappa ~ 800 the exit iteration depends on the summation order -- the oracle's own four
+    # order variants (FMA contraction on / off x tree / sequential reduce, oracle/pcg_oracle.h) need not agree with each
+    # other.  The GPU count has to lie in the band those variants span, widened by one on each side.
+    band = np.stack([orc.pcg_batch(n, N, B, S32, Ph, g32, tol=1e-6, max_iter=300, flags=f)["iters"].astype(np.int64)
+                     for f in range(4)])
+    gi = out["iters"].astype(np.int64)
+    assert (gi >= band.min(axis=0) - 1).all() and (gi <= band.max(axis=0) + 1).all(), (gi, band)
+    assert np.abs(gi - o32["iters"].astype(np.int64)).max() <= 1 + (band.max(axis=0) - band.min(axis=0)).max()
     for b in range(B):
         e_gpu, e_orc = relerr(out["lambda_"][b], truth["lambda_"][b]), relerr(o32["lambda_"][b], truth["lambda_"][b])
         assert e_gpu < 1.5 * e_orc + 1e-6
