@@ -32,6 +32,9 @@
 #ifndef GBDPCG_RS_PREFETCH
 #define GBDPCG_RS_PREFETCH 1
 #endif
+#ifndef GBDPCG_RS_LINEAR_PAIRS
+#define GBDPCG_RS_LINEAR_PAIRS 0   // 1: the round-1 assignment of block-row pairs to groups (A/B builds)
+#endif
 
 namespace gbdpcg {
 
@@ -337,7 +340,16 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     const uint32_t dump = (uint32_t)(uintptr_t)(ls + align16<float>(len));
 
     const uint32_t rp = lane & 7u;
-    const uint32_t k0 = 2 * (wave * G::GROUPS + (lane >> 3)), k1 = k0 + 1;
+    // Which pair of block-rows a group owns is free; it is chosen so that the four groups that share an LDS pass
+    // (lanes 0-31 / 32-63 of a wave) own pairs j, j+4, j+8, j+12: their rows of a vector then start 48 banks apart
+    // (a pair is 2n = 28 floats) and the 8-byte accesses of 4 x 7 lanes tile the 64 banks instead of colliding two by
+    // two, as consecutive pairs do (bases 0, 28, 56, 20 mod 64: 13 % of an iteration's LDS-array cycles were conflicts).
+    const uint32_t grp = lane >> 3;
+#if GBDPCG_RS_LINEAR_PAIRS
+    const uint32_t k0 = 2 * (wave * G::GROUPS + grp), k1 = k0 + 1;
+#else
+    const uint32_t k0 = 2 * (16 * (wave >> 1) + 4 * (grp & 3u) + 2 * (wave & 1u) + (grp >> 2)), k1 = k0 + 1;
+#endif
     const bool live0 = rp < n / 2 && k0 < N, live1 = rp < n / 2 && k1 < N;
     const uint32_t row0 = (live0 ? k0 * n + rp * 2 : 0u), row1 = (live1 ? k1 * n + rp * 2 : 0u);
     // x operand windows inside a padded mirror (n zeros before x_0 and after x_{N-1}); dead lanes read row 0
