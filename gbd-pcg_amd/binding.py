@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GBDPCG_LIB") or os.path.join(CSRC, "libgbdpcg.so")
 
 OK = 0
-PATH_AUTO, PATH_FUSED, PATH_SPLIT, PATH_PERSISTENT = 0, 1, 2, 3
+PATH_AUTO, PATH_FUSED, PATH_SPLIT, PATH_PERSISTENT, PATH_PERSISTENT_1R = 0, 1, 2, 3, 4
 PINV_IDENTITY, PINV_BLOCK_JACOBI, PINV_STAIR = 0, 1, 2
 
 # every symbol include/gbdpcg.h declares (checked by tests/test_abi.py)

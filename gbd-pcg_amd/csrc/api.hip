@@ -121,7 +121,8 @@ template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint3
 {
     const bool fits = fused_fits<T>(h->dev, n, N);
     const bool persist = persist_knots_per_wg<T>(h->dev, n, N, batch) != 0;
-    if (h->forced == GBDPCG_PATH_PERSISTENT) return persist ? GBDPCG_PATH_PERSISTENT : (fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT);
+    if (h->forced == GBDPCG_PATH_PERSISTENT || h->forced == GBDPCG_PATH_PERSISTENT_1R)
+        return persist ? h->forced : (fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT);
     if (h->forced == GBDPCG_PATH_FUSED) return fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT;
     if (h->forced == GBDPCG_PATH_SPLIT) return GBDPCG_PATH_SPLIT;
     // A problem too large for one workgroup: one persistent launch over many CUs when all of its workgroups can be
@@ -206,7 +207,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
     DEVICE_SCOPE(h);
     const gbdpcg_path path = pick_path<T>(h, n, N, batch);
-    if (path == GBDPCG_PATH_PERSISTENT) {
+    if (path == GBDPCG_PATH_PERSISTENT || path == GBDPCG_PATH_PERSISTENT_1R) {
         const size_t need = persist_workspace_bytes<T>(n, N, batch);
         if (need > h->pws_bytes) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -214,7 +215,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
             gbdpcg_status st = ensure_pws(h, need);
             if (st != GBDPCG_OK) return st;
         }
-        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, h->pws, stream));
+        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, h->pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
     } else if (path == GBDPCG_PATH_FUSED) {
         const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
         if (has_sym && h->symmetric == 2 && given_verdict_stride) {
@@ -409,7 +410,7 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     *out = nullptr;
     if (!shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     DEVICE_SCOPE(h);
-    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT) {
+    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT || pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT_1R) {
         gbdpcg_status st = ensure_pws(h, persist_workspace_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
     } else if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
@@ -565,7 +566,7 @@ const char *gbdpcg_last_hip_error_string(gbdpcg_handle_t h)
 
 gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path)
 {
-    if (!h || (int)path < 0 || (int)path > 3) return GBDPCG_ERR_INVALID;
+    if (!h || (int)path < 0 || (int)path > 4) return GBDPCG_ERR_INVALID;
     h->forced = path;
     return GBDPCG_OK;
 }
@@ -638,11 +639,11 @@ size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n,
     if (elem_size == 8) {
         const gbdpcg_path p = pick_path<double>(h, n, N, batch);
         if (p == GBDPCG_PATH_FUSED) return 0;
-        return p == GBDPCG_PATH_PERSISTENT ? persist_workspace_bytes<double>(n, N, batch) : split_workspace_bytes<double>(n, N, batch);
+        return (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) ? persist_workspace_bytes<double>(n, N, batch) : split_workspace_bytes<double>(n, N, batch);
     }
     const gbdpcg_path p = pick_path<float>(h, n, N, batch);
     if (p == GBDPCG_PATH_FUSED) return 0;
-    return p == GBDPCG_PATH_PERSISTENT ? persist_workspace_bytes<float>(n, N, batch) : split_workspace_bytes<float>(n, N, batch);
+    return (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) ? persist_workspace_bytes<float>(n, N, batch) : split_workspace_bytes<float>(n, N, batch);
 }
 
 gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)
@@ -653,7 +654,7 @@ gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, 
     gbdpcg_status st = ensure_sym_flags(h, elem_size == 8 ? verdict_bytes<double>(n, N, batch) : verdict_bytes<float>(n, N, batch));
     if (st != GBDPCG_OK) return st;
     const gbdpcg_path p = elem_size == 8 ? pick_path<double>(h, n, N, batch) : pick_path<float>(h, n, N, batch);
-    if (p == GBDPCG_PATH_PERSISTENT) return ensure_pws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
+    if (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) return ensure_pws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
     return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
 }
 

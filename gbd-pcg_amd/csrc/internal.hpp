@@ -106,7 +106,8 @@ template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint3
 template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
 // workspace: persist_workspace_bytes, ZERO-FILLED once when allocated (epoch bases live there), never cleared again
 template <typename T>
-hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s);
+hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,
+                              bool one_reduction = false);   // one_reduction: the Chronopoulos-Gear form (opt-in path 4)
 
 // ---- symcheck.hip : flags[b] = 1 iff L_{k+1} == R_k^T bit for bit for every k of problem b
 // and_into: flags[b] &= result instead of flags[b] = result (second matrix of a pair).

@@ -81,15 +81,20 @@ constexpr uint32_t kPartStrideWords = GBDPCG_PERSIST_PSTRIDE / 8;
 #define GBDPCG_PERSIST_SLEEP0 0
 #endif
 
-// Workspace of one problem, in u64 words: [ctrl | part[2][N] slots | halo[2][N][2][n] values], sized for one knot
+// Workspace of one problem, in u64 words: [ctrl | part[2][N] slots | halo[2][N][2][n] values | halo2 (same)], sized for one knot
 // per workgroup (the largest workgroup count), whatever K a launch uses.
 template <typename T> __host__ __device__ inline size_t persist_part_words(uint32_t N)
 {
     return (size_t)2 * N * (kPartStrideWords > Gran<T>::PER ? kPartStrideWords : Gran<T>::PER);
 }
+template <typename T> __host__ __device__ inline size_t persist_halo_words(uint32_t n, uint32_t N)
+{
+    return (size_t)2 * N * 2 * n * Gran<T>::PER;
+}
+// ... followed by a second halo region of the same size, used by the single-reduction kernel only (its extra hand-off)
 template <typename T> __host__ __device__ inline size_t persist_words(uint32_t n, uint32_t N)
 {
-    return kPersistCtrl + persist_part_words<T>(N) + (size_t)2 * N * 2 * n * Gran<T>::PER;
+    return kPersistCtrl + persist_part_words<T>(N) + 2 * persist_halo_words<T>(n, N);
 }
 
 // Wave 0 of a workgroup: poll until every partial of this epoch and the two neighbour boundary vectors have
@@ -101,26 +106,31 @@ template <typename T> __host__ __device__ inline size_t persist_words(uint32_t n
 #ifndef GBDPCG_PERSIST_GAP
 #define GBDPCG_PERSIST_GAP 1
 #endif
-template <typename T, int NCT, uint32_t PJ>
+template <typename T, int NCT, uint32_t PJ, uint32_t NV>
 __device__ __forceinline__ bool persist_sweep_w(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
-                                                uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit, T &total,
+                                                uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit, T (&total)[NV ? NV : 1],
                                                 T *yl, T *yr)
 {
+    // NV values per partial slot, adjacent (0: neighbours only, nothing is summed)
     constexpr uint32_t PER = Gran<T>::PER, PSTRIDE = (kPartStrideWords > PER ? kPartStrideWords : PER) * 8;
+    constexpr uint32_t NS = NV ? PJ * NV : 1;
     static_assert(NCT <= 64, "one halo value per lane");
-    T pv[PJ], hl = T(0), hr = T(0);
-    bool have[PJ], have_l = hl_off < 0 || lane >= (uint32_t)NCT, have_r = hr_off < 0 || lane >= (uint32_t)NCT;
+    static_assert(NV * PER * 8 <= PSTRIDE, "the values of a slot share its line");
+    T pv[NS], hl = T(0), hr = T(0);
+    bool have[NS], have_l = hl_off < 0 || lane >= (uint32_t)NCT, have_r = hr_off < 0 || lane >= (uint32_t)NCT;
 #pragma unroll
-    for (uint32_t j = 0; j < PJ; ++j) {
+    for (uint32_t j = 0; j < NS; ++j) {
         pv[j] = T(0);
-        have[j] = lane + 64 * j >= W;
+        have[j] = NV == 0 || lane + 64 * (j / (NV ? NV : 1)) >= W;
     }
     if (GBDPCG_PERSIST_SLEEP0) __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_SLEEP0);
     for (uint32_t spins = 0;; ++spins) {
         bool all = true;
 #pragma unroll
-        for (uint32_t j = 0; j < PJ; ++j) {
-            if (!have[j]) have[j] = slot_load(region, part_off + (lane + 64 * j) * PSTRIDE, epoch, pv[j]);
+        for (uint32_t j = 0; j < NS; ++j) {
+            if (!have[j])
+                have[j] = slot_load(region, part_off + (lane + 64 * (j / (NV ? NV : 1))) * PSTRIDE + (j % (NV ? NV : 1)) * PER * 8,
+                                    epoch, pv[j]);
             all = all && have[j];
         }
         if (!have_l) have_l = slot_load(region, (uint32_t)hl_off + lane * PER * 8, epoch, hl);
@@ -129,25 +139,40 @@ __device__ __forceinline__ bool persist_sweep_w(__amdgpu_buffer_rsrc_t region, u
         if (spins >= spin_limit) return false;
         __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_GAP);
     }
-    T s = pv[0];
+    if constexpr (NV > 0) {
 #pragma unroll
-    for (uint32_t j = 1; j < PJ; ++j) s += pv[j];
-    total = wave_sum(s);
+        for (uint32_t v = 0; v < NV; ++v) {
+            T sum = pv[v];
+#pragma unroll
+            for (uint32_t j = 1; j < PJ; ++j) sum += pv[j * NV + v];
+            total[v] = wave_sum(sum);
+        }
+    }
     if (lane < (uint32_t)NCT) {
         yl[lane] = hl;
         yr[lane] = hr;
     }
     return true;
 }
+// partial slots per lane by workgroup count: the sums of the three forms differ only in how many zeros they add
+template <typename T, int NCT, uint32_t NV>
+__device__ __forceinline__ bool persist_sweep_n(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
+                                                uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit,
+                                                T (&total)[NV ? NV : 1], T *yl, T *yr)
+{
+    if (NV == 0 || W <= 64) return persist_sweep_w<T, NCT, 1, NV>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    if (W <= 128) return persist_sweep_w<T, NCT, 2, NV>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    return persist_sweep_w<T, NCT, 4, NV>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+}
 template <typename T, int NCT>
 __device__ __forceinline__ bool persist_sweep(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
                                               uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit, T &total,
                                               T *yl, T *yr)
 {
-    // partial slots per lane: the sums differ between the three forms only in how many zeros they add
-    if (W <= 64) return persist_sweep_w<T, NCT, 1>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
-    if (W <= 128) return persist_sweep_w<T, NCT, 2>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
-    return persist_sweep_w<T, NCT, 4>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    T tot[1];
+    const bool ok = persist_sweep_n<T, NCT, 1>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, tot, yl, yr);
+    total = tot[0];
+    return ok;
 }
 
 // acc = sum_i m[i] * (A[i] + coef * B[i]) over this thread's COLS columns, ascending.  The operands come out of LDS
@@ -433,6 +458,242 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
     }
 }
 
+// ---- single-reduction variant (opt-in: GBDPCG_PATH_PERSISTENT_1R) ------------------------------------------------------
+// The same solve in the Chronopoulos-Gear form of preconditioned CG: u = Pinv r, w = S u, and BOTH inner products
+// gamma = r.u, delta = u.w travel in ONE all-gather per iteration (the north star's "single cross-CU reduction per
+// iteration"); the boundary knots of u go to the two neighbours only (no all-to-all) before w can be formed:
+//     beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)        (beta = 0, alpha = gamma / delta first)
+//     p = u + beta p ; s = w + beta s ; lambda += alpha p ; r -= alpha s
+// In exact arithmetic p, lambda, r and the tested quantity gamma_i = r_i . Pinv r_i are those of pcg.cuh:154-206 (the exit
+// test |gamma| < tol is the same test, seen one product pair later); the ROUNDING sequence differs (alpha is not
+// eta / (p . S p) and s = S p is updated by recurrence), which is why AUTO never picks this kernel: the reference's
+// recurrence stays the default.  Measured against the oracle: equal iteration counts and fp64 lambda within 1e-13 on
+// every shape of tests/test_gpu_persist.py (a = 0.5 and a = 0.9 generators).
+template <typename T, int NCT, int K, bool HAS_PINV>
+__global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_kernel(PcgArgs<T> a, u64 *ws_all, uint32_t W,
+                                                                                       uint32_t spin_limit)
+{
+    using Gm = PersistGeom<T, NCT>;
+    constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
+    constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0;
+    constexpr uint32_t WIN = (K + 2) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n;
+    static_assert(3 * n <= G * COLS && THREADS <= 1024, "lane map");
+    static_assert((n * sizeof(T)) % 16 == 0 && (COLS * sizeof(T)) % 16 == 0, "operand runs start on 16-byte boundaries");
+
+    __shared__ __attribute__((aligned(16))) T rwin[WINP], pwin[WINP], swin[WINP], uwin[WINP], wwin[WINP], lwin[WINP];
+    __shared__ __attribute__((aligned(16))) T lam[OWN];
+    __shared__ T dots_g[NWAVES], dots_d[NWAVES];
+    __shared__ T bc[4];          // [0] alpha, [1] beta, [2] gamma_old, [3] alpha_old
+    __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out, 3 ran out), [1] iterations
+
+    const uint32_t N = a.N, len = n * N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t slot = wave / WPK, wv = wave - slot * WPK;
+    const uint32_t g = lane & 7u, row = wv * 8 + (lane >> 3);
+    const bool row_live = row < n;
+    const uint32_t cbase = g * COLS;
+    const uint32_t oi = slot * n + (row_live ? row : 0u);
+
+    const uint32_t prob = blockIdx.x / W, b = blockIdx.x - prob * W;
+    const uint32_t w = (W % 8 == 0) ? (b % 8) * (W / 8) + b / 8 : b;   // neighbours on one XCD (speed only)
+    const uint32_t k0 = w * K, k = k0 + slot;
+    const bool knot_live = k < N;
+
+    const size_t mstride = (size_t)3 * n * n * N;
+    const T *S = a.S + prob * mstride;
+    const T *P = HAS_PINV ? a.Pinv + prob * mstride : nullptr;
+    const T *gamma = a.gamma + (size_t)prob * len;
+    T *lambda = a.lambda + (size_t)prob * len;
+
+    u64 *ws = ws_all + (size_t)prob * persist_words<T>(n, N);
+    constexpr uint32_t PSW = kPartStrideWords > 2 * PER ? kPartStrideWords : 2 * PER;
+    static_assert(PSW == kPartStrideWords, "two values per partial slot fit the slot stride");
+    u64 *part = ws + kPersistCtrl;                                   // [2][N] slots of {gamma, delta}
+    u64 *halo_w = part + persist_part_words<T>(N);                   // [2][N][2][n]: boundary knots of r (prologue) and w
+    u64 *halo_u = halo_w + persist_halo_words<T>(n, N);              // [2][N][2][n]: boundary knots of u
+    const __amdgpu_buffer_rsrc_t region = __builtin_amdgcn_make_buffer_rsrc(
+        part, 0, (int)((persist_words<T>(n, N) - kPersistCtrl) * 8), 0x00020000);
+    const uint32_t hw_base = (uint32_t)(persist_part_words<T>(N) * 8);
+    const uint32_t hu_base = hw_base + (uint32_t)(persist_halo_words<T>(n, N) * 8);
+    const uint32_t base = (uint32_t)__hip_atomic_load(ws, GBDPCG_RLX_AGENT);
+
+    T sreg[COLS], preg[COLS];
+    {
+        const T *Sk = S + (size_t)(knot_live ? k : 0u) * 3 * n * n;
+        const T *Pk = (HAS_PINV ? P : S) + (size_t)(knot_live ? k : 0u) * 3 * n * n;
+        T sraw[COLS], praw[COLS];
+#pragma unroll
+        for (uint32_t i = 0; i < COLS; ++i) {
+            const uint32_t c = cbase + i;
+            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
+            const uint32_t idx = valid ? c * n + row : n * n;
+            sraw[i] = Sk[idx];
+            if (HAS_PINV) praw[i] = Pk[idx];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t i = 0; i < COLS; ++i) {
+            const uint32_t c = cbase + i;
+            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
+            sreg[i] = valid ? sraw[i] : T(0);
+            if (HAS_PINV) preg[i] = valid ? praw[i] : T(0);
+            else preg[i] = (valid && c == n + row) ? T(1) : T(0);
+        }
+    }
+
+    for (uint32_t i = tid; i < WINP; i += THREADS) {
+        rwin[i] = pwin[i] = swin[i] = uwin[i] = wwin[i] = T(0);
+        const int64_t gi = (int64_t)k0 * n - n + i;
+        lwin[i] = (i < WIN && gi >= 0 && gi < (int64_t)len) ? lambda[gi] : T(0);
+    }
+    for (uint32_t i = tid; i < OWN; i += THREADS) lam[i] = (k0 * n + i < len) ? lambda[k0 * n + i] : T(0);
+    if (tid == 0) {
+        bc[0] = bc[1] = bc[2] = bc[3] = T(0);
+        bci[0] = bci[1] = 0u;
+    }
+    __syncthreads();
+
+    // hand-off slot offsets (bytes from `part`) of this workgroup's neighbours, by buffer parity
+    auto nbr_l = [&](uint32_t hbase, uint32_t par) { return w > 0 ? (int)(hbase + ((par * N + (w - 1)) * 2 + 1) * n * PER * 8u) : -1; };
+    auto nbr_r = [&](uint32_t hbase, uint32_t par) { return w + 1 < W ? (int)(hbase + ((par * N + (w + 1)) * 2) * n * PER * 8u) : -1; };
+
+    // One product y = M X over the own knots (X a complete window in LDS), y's own part into YWIN, and the workgroup's
+    // shares d1 = sum D1own * y (and d2 = sum D2own * y) into dots_g / dots_d.  Ends with the barrier behind which the
+    // publishing wave and the polling wave take over.
+#define GBDPCG_1R_PRODUCT(MREG, XWIN, YWIN, D1, D2, INIT)                                                        \
+    {                                                                                                             \
+        T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768)>(MREG, (XWIN) + slot * n + cbase, (XWIN) + slot * n + cbase, T(0))); \
+        T d1 = T(0), d2 = T(0);                                                                                   \
+        if (g == 0 && row_live) {                                                                                 \
+            if (INIT) y = (knot_live ? gamma[k * n + row] : T(0)) - y;                                            \
+            (YWIN)[n + oi] = y;                                                                                   \
+            if ((D1) != nullptr) d1 = (D1)[n + oi] * y;                                                           \
+            if ((D2) != nullptr) d2 = (D2)[n + oi] * y;                                                           \
+        }                                                                                                         \
+        d1 = wave_sum(d1);                                                                                        \
+        d2 = wave_sum(d2);                                                                                        \
+        if (lane == 0) {                                                                                          \
+            if ((D1) != nullptr) dots_g[wave] = d1;                                                               \
+            if ((D2) != nullptr) dots_d[wave] = d2;                                                               \
+        }                                                                                                         \
+        __syncthreads();                                                                                          \
+    }
+    // wave PUB: the two boundary knots of YWIN for the neighbours
+#define GBDPCG_1R_PUBLISH_HALO(HALO, YWIN, PAR, TAG)                                                              \
+    {                                                                                                             \
+        u64 *my_halo = (HALO) + (((size_t)(PAR) * N + w) * 2) * n * PER;                                          \
+        for (uint32_t i = lane; i < 2 * n; i += 64) {                                                             \
+            const uint32_t src = i < n ? n + i : n + (K - 1) * n + (i - n);                                        \
+            gran_store(my_halo + (size_t)i * PER, (TAG), (YWIN)[src]);                                            \
+        }                                                                                                         \
+    }
+
+    T *const none = nullptr;
+    // r = gamma - S lambda (pcg.cuh:118-126); its boundary knots go to the neighbours with epoch 1
+    GBDPCG_1R_PRODUCT(sreg, lwin, rwin, none, none, true)
+    if (wave == PUB) GBDPCG_1R_PUBLISH_HALO(halo_w, rwin, 1u, base + 1u)
+    if (wave == 0) {
+        T dummy[1];
+        const bool ok = persist_sweep_n<T, NCT, 0>(region, 0u, nbr_l(hw_base, 1u), nbr_r(hw_base, 1u), W, base + 1u, lane, spin_limit,
+                                                   dummy, rwin, rwin + n + OWN);
+        if (lane == 0 && !ok) bci[0] = 2u;
+    }
+    __syncthreads();
+
+    uint32_t iter = 0;
+    for (; bci[0] == 0u; ++iter) {
+        const uint32_t eu = 2u + 2u * iter, ew = 3u + 2u * iter, par = iter & 1u;
+        // u = Pinv r ; share of gamma = r . u ; boundary knots of u to the two neighbours      (pcg.cuh:180-187)
+        GBDPCG_1R_PRODUCT(preg, rwin, uwin, rwin, none, false)
+        if (wave == PUB) GBDPCG_1R_PUBLISH_HALO(halo_u, uwin, par, base + eu)
+        if (wave == 0) {
+            T dummy[1];
+            const bool ok = persist_sweep_n<T, NCT, 0>(region, 0u, nbr_l(hu_base, par), nbr_r(hu_base, par), W, base + eu, lane,
+                                                       spin_limit, dummy, uwin, uwin + n + OWN);
+            if (lane == 0 && !ok) bci[0] = 2u;
+        }
+        __syncthreads();
+        if (bci[0] != 0u) break;
+        // w = S u ; share of delta = u . w ; {gamma, delta, boundary knots of w} in ONE all-gather
+        GBDPCG_1R_PRODUCT(sreg, uwin, wwin, none, uwin, false)
+        if (wave == PUB) {
+            GBDPCG_1R_PUBLISH_HALO(halo_w, wwin, par, base + ew)
+            T pg = dots_g[0], pd = dots_d[0];
+#pragma unroll
+            for (uint32_t q = 1; q < NWAVES; ++q) {
+                pg += dots_g[q];
+                pd += dots_d[q];
+            }
+            if (lane == 0) {
+                u64 *slot_p = part + ((size_t)par * N + w) * PSW;
+                gran_store(slot_p, base + ew, pg);
+                gran_store(slot_p + PER, base + ew, pd);
+            }
+        }
+        if (wave == 0) {
+            T tot[2];
+            const bool ok = persist_sweep_n<T, NCT, 2>(region, par * N * PSW * 8u, nbr_l(hw_base, par), nbr_r(hw_base, par), W, base + ew,
+                                                       lane, spin_limit, tot, wwin, wwin + n + OWN);
+            if (lane == 0) {
+                const T gam = tot[0], del = tot[1];
+                if (!ok) {
+                    bci[0] = 2u;
+                } else if (iter > 0 && fabs(gam) < a.tol) {       // pcg.cuh:195, on gamma_iter = r . Pinv r after `iter` updates
+                    bci[0] = 1u;
+                    bci[1] = iter;
+                } else if (iter >= a.max_iter) {
+                    bci[0] = 3u;
+                    bci[1] = a.max_iter;
+                    bc[1] = iter > 0 ? gam / bc[2] : T(0);        // the beta of the direction update the reference still runs
+                } else {
+                    const T beta = iter > 0 ? gam / bc[2] : T(0);
+                    const T alpha = iter > 0 ? gam / (del - beta * gam / bc[3]) : gam / del;
+                    bc[0] = alpha;
+                    bc[1] = beta;
+                    bc[2] = gam;
+                    bc[3] = alpha;
+                }
+            }
+        }
+        __syncthreads();
+        if (bci[0] != 0u) break;
+        // p = u + beta p ; s = w + beta s ; lambda += alpha p ; r -= alpha s   (own and halo knots: element-wise, in place)
+        {
+            const T alpha = bc[0], beta = bc[1];
+            for (uint32_t i = tid; i < WIN; i += THREADS) {
+                const T pn = fma_t(beta, pwin[i], uwin[i]);
+                const T sn = fma_t(beta, swin[i], wwin[i]);
+                pwin[i] = pn;
+                swin[i] = sn;
+                rwin[i] = fma_t(-alpha, sn, rwin[i]);
+                if (i >= n && i < n + OWN) lam[i - n] = fma_t(alpha, pn, lam[i - n]);
+            }
+        }
+        __syncthreads();
+    }
+#undef GBDPCG_1R_PRODUCT
+#undef GBDPCG_1R_PUBLISH_HALO
+
+    // ---- outputs (pcg.cuh:212,215) --------------------------------------------------------------------------------
+    const uint32_t stop = bci[0];
+    const bool failed = stop == 2u, ran_out = stop == 3u;
+    const T beta = ran_out ? bc[1] : T(0);   // max-iteration exit: the reference's last iteration still ran p = r~ + beta p
+    for (uint32_t i = tid; i < OWN; i += THREADS) {
+        const uint32_t gi = k0 * n + i;
+        if (gi < len) {
+            lambda[gi] = lam[i];
+            if (a.r) a.r[(size_t)prob * len + gi] = rwin[n + i];
+            if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pwin[n + i], uwin[n + i]) : (bci[1] == 0u && !failed ? uwin[n + i] : pwin[n + i]);
+        }
+    }
+    if (w == 0 && tid == 0) {
+        a.iters[prob] = failed ? 0xffffffffu : bci[1];
+        if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (ran_out ? 1 : 0);
+        __hip_atomic_store(ws, (u64)(base + 2u * a.max_iter + 8u), GBDPCG_RLX_AGENT);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 #define GBDPCG_PERSIST_N(X) X(36)
@@ -470,30 +731,33 @@ template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uin
 }
 
 template <typename T, int NCT, int K>
-static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStream_t s)
+static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction)
 {
     const uint32_t W = (a.N + K - 1) / K;
     // ~1 us per failed pass: a launch whose workgroups are not all resident gives up after about two seconds
     const uint32_t spin_limit = 1u << 21;
-    if (a.Pinv)
-        hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, true>), dim3(W * a.batch), dim3(K * PersistGeom<T, NCT>::TPK), 0,
-                           s, a, reinterpret_cast<u64 *>(workspace), W, spin_limit);
-    else
-        hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, false>), dim3(W * a.batch), dim3(K * PersistGeom<T, NCT>::TPK), 0,
-                           s, a, reinterpret_cast<u64 *>(workspace), W, spin_limit);
+    const dim3 grid(W * a.batch), block(K * PersistGeom<T, NCT>::TPK);
+    u64 *ws = reinterpret_cast<u64 *>(workspace);
+    if (one_reduction) {
+        if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
+        else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
+    } else {
+        if (a.Pinv) hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
+        else hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
+    }
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s)
+hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction)
 {
     const uint32_t K = persist_knots_per_wg<T>(dev, a.n, a.N, a.batch);
     if (K == 0 || workspace == nullptr) return hipErrorInvalidValue;
-#define GBDPCG_CASE(NN)                                                       \
-    if (a.n == NN) {                                                          \
-        if (K == 1) return launch_persist_k<T, NN, 1>(a, workspace, s);       \
-        if (K == 2) return launch_persist_k<T, NN, 2>(a, workspace, s);       \
-        return launch_persist_k<T, NN, 3>(a, workspace, s);                   \
+#define GBDPCG_CASE(NN)                                                                       \
+    if (a.n == NN) {                                                                          \
+        if (K == 1) return launch_persist_k<T, NN, 1>(a, workspace, s, one_reduction);        \
+        if (K == 2) return launch_persist_k<T, NN, 2>(a, workspace, s, one_reduction);        \
+        return launch_persist_k<T, NN, 3>(a, workspace, s, one_reduction);                    \
     }
     GBDPCG_PERSIST_N(GBDPCG_CASE)
 #undef GBDPCG_CASE
@@ -504,7 +768,7 @@ template uint32_t persist_knots_per_wg<float>(const DeviceInfo &, uint32_t, uint
 template uint32_t persist_knots_per_wg<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
 template size_t persist_workspace_bytes<float>(uint32_t, uint32_t, uint32_t);
 template size_t persist_workspace_bytes<double>(uint32_t, uint32_t, uint32_t);
-template hipError_t launch_pcg_persist<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t);
-template hipError_t launch_pcg_persist<double>(const DeviceInfo &, const PcgArgs<double> &, void *, hipStream_t);
+template hipError_t launch_pcg_persist<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t, bool);
+template hipError_t launch_pcg_persist<double>(const DeviceInfo &, const PcgArgs<double> &, void *, hipStream_t, bool);
 
 }  // namespace gbdpcg

@@ -62,7 +62,7 @@ def main():
         it = torch.zeros(B, dtype=torch.int32, device="cuda")
         fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
         mat = (3 * N - 2) * n * n * es
-        for path, pname in ((binding.PATH_FUSED, "fused"), (binding.PATH_SPLIT, "split"), (binding.PATH_PERSISTENT, "persist")):
+        for path, pname in ((binding.PATH_FUSED, "fused"), (binding.PATH_SPLIT, "split"), (binding.PATH_PERSISTENT, "persist"), (binding.PATH_PERSISTENT_1R, "persist1r")):
             solver.set_path(path)
             chosen = solver.choose_path(es, n, N, B)
             if chosen != path:

@@ -55,13 +55,19 @@ typedef enum gbdpcg_path {
     GBDPCG_PATH_AUTO = 0,
     GBDPCG_PATH_FUSED = 1, /* one workgroup per problem, vectors LDS-resident, one launch per solve */
     GBDPCG_PATH_SPLIT = 2, /* many workgroups per problem, two launches per iteration, vectors in L2/HBM */
-    GBDPCG_PATH_PERSISTENT = 3 /* one large problem over many CUs in ONE launch: block-rows register-resident for the
+    GBDPCG_PATH_PERSISTENT = 3, /* one large problem over many CUs in ONE launch: block-rows register-resident for the
                                   whole solve (the reference's layout, pcg.cuh:104-110), two in-kernel all-gathers of
                                   {partial inner product, boundary knots} per iteration instead of 4 grid.sync().  Needs
                                   every workgroup resident at once (ceil(N/K) * batch <= CU count, K <= 4): do not run
                                   other kernels on the device concurrently.  A launch that cannot get its workgroups
                                   resident gives up after a bounded spin and reports d_max_iter_exit = 2,
                                   d_iters = 0xffffffff (result invalid; use GBDPCG_PATH_SPLIT for such callers). */
+    GBDPCG_PATH_PERSISTENT_1R = 4 /* OPT-IN, never chosen by AUTO: the persistent launch with the single-reduction
+                                  (Chronopoulos-Gear) recurrence -- u = Pinv r, w = S u, gamma = r.u and delta = u.w in ONE
+                                  all-gather per iteration, alpha = gamma / (delta - beta gamma / alpha_old), s = S p by
+                                  recurrence.  Same iterates and the same exit test as pcg.cuh:154-206 in exact arithmetic,
+                                  a different rounding sequence: equal iteration counts and fp64 lambda within 1e-13 of the
+                                  default path on the test shapes, but not the reference's recurrence. */
 } gbdpcg_path;
 
 /* Preconditioners gbdpcg_form_pinv can build from S. */
