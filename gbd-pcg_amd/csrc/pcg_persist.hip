@@ -179,28 +179,33 @@ __device__ __forceinline__ bool persist_sweep(__amdgpu_buffer_rsrc_t region, uin
 // in 16-byte pieces, STEP columns per step.  FENCED (three knots per workgroup: 960 threads, 128 VGPRs): the steps are
 // pinned in order, because left alone hipcc hoists all 2 * COLS reads above the first multiply and spills; with fewer
 // threads the hoisting is what we want (one LDS latency per product instead of one per step).
-template <typename T, uint32_t COLS, bool FENCED>
+template <typename T, uint32_t COLS, bool FENCED, bool ALIGNED = true>
 __device__ __forceinline__ T persist_row_dot(const T (&m)[COLS], const T *A, const T *B, T coef)
 {
-    constexpr uint32_t VW = 16 / sizeof(T), STEP = COLS % 4 == 0 ? 4 : VW;
-    static_assert(COLS % STEP == 0 && STEP % VW == 0, "columns per thread come in whole 16-byte pieces");
-    typedef T vec_t __attribute__((ext_vector_type(VW)));
     T acc = T(0);
+    if constexpr (ALIGNED) {
+        constexpr uint32_t VW = 16 / sizeof(T), STEP = COLS % 4 == 0 ? 4 : VW;
+        static_assert(COLS % STEP == 0 && STEP % VW == 0, "columns per thread come in whole 16-byte pieces");
+        typedef T vec_t __attribute__((ext_vector_type(VW)));
 #pragma unroll
-    for (uint32_t i0 = 0; i0 < COLS; i0 += STEP) {
-        T av[STEP], bv[STEP];
+        for (uint32_t i0 = 0; i0 < COLS; i0 += STEP) {
+            T av[STEP], bv[STEP];
 #pragma unroll
-        for (uint32_t q = 0; q < STEP / VW; ++q) {
-            const vec_t va = *reinterpret_cast<const vec_t *>(A + i0 + q * VW), vb = *reinterpret_cast<const vec_t *>(B + i0 + q * VW);
+            for (uint32_t q = 0; q < STEP / VW; ++q) {
+                const vec_t va = *reinterpret_cast<const vec_t *>(A + i0 + q * VW), vb = *reinterpret_cast<const vec_t *>(B + i0 + q * VW);
 #pragma unroll
-            for (uint32_t e = 0; e < VW; ++e) {
-                av[q * VW + e] = va[e];
-                bv[q * VW + e] = vb[e];
+                for (uint32_t e = 0; e < VW; ++e) {
+                    av[q * VW + e] = va[e];
+                    bv[q * VW + e] = vb[e];
+                }
             }
-        }
 #pragma unroll
-        for (uint32_t j = 0; j < STEP; ++j) acc = fma_t(m[i0 + j], fma_t(coef, bv[j], av[j]), acc);
-        if (FENCED) __builtin_amdgcn_sched_barrier(0);
+            for (uint32_t j = 0; j < STEP; ++j) acc = fma_t(m[i0 + j], fma_t(coef, bv[j], av[j]), acc);
+            if (FENCED) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {   // block sizes whose rows are not multiples of 16 bytes (n = 14 in fp32): element-wise LDS reads
+#pragma unroll
+        for (uint32_t i = 0; i < COLS; ++i) acc = fma_t(m[i], fma_t(coef, B[i], A[i]), acc);
     }
     return acc;
 }
@@ -233,7 +238,10 @@ enum PersistPhase { PP_INIT = 0, PP_PRECOND = 1, PP_DIRECTION = 2 };
 // no LDS round trip and no barrier of its own.
 template <typename T, int NCT> struct PersistGeom {
     static constexpr uint32_t n = NCT, G = 8, WPK = (n + 7) / 8, TPK = WPK * 64, VW = 16 / sizeof(T);
-    static constexpr uint32_t COLS = ((3 * n + G - 1) / G + VW - 1) / VW * VW;
+    static constexpr uint32_t CPL = (3 * n + G - 1) / G;   // columns per lane
+    // 16-byte operand reads need the knots of a window and the lanes' column runs on 16-byte boundaries
+    static constexpr bool ALIGNED = (n * sizeof(T)) % 16 == 0 && ((CPL + VW - 1) / VW * VW * sizeof(T)) % 16 == 0;
+    static constexpr uint32_t COLS = ALIGNED ? (CPL + VW - 1) / VW * VW : CPL;
 };
 
 template <typename T, int NCT, int K, bool HAS_PINV>
@@ -245,7 +253,6 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
     constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0;   // PUB: the publishing wave
     constexpr uint32_t WIN = (K + 2) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n;
     static_assert(3 * n <= G * COLS && THREADS <= 1024, "lane map");
-    static_assert((n * sizeof(T)) % 16 == 0 && (COLS * sizeof(T)) % 16 == 0, "operand runs start on 16-byte boundaries");
 
     __shared__ __attribute__((aligned(16))) T rwin[2][WINP];
     __shared__ __attribute__((aligned(16))) T pwin[2][WINP];
@@ -353,7 +360,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
                 (NEW)[j] = fma_t(coef, (B)[j], (A)[j]);                                                              \
             }                                                                                                        \
         }                                                                                                            \
-        T y = persist_row_dot<T, COLS, (THREADS > 768)>(MREG, (A) + slot * n + cbase, (B) + slot * n + cbase, coef);   \
+        T y = persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(MREG, (A) + slot * n + cbase, (B) + slot * n + cbase, coef);   \
         GBDPCG_STAMP(1, stamp_here && PHASE == PP_DIRECTION)                                                         \
         y = group_sum8(y);                                                                                           \
         T d = T(0);                                                                                                  \
@@ -478,7 +485,6 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
     constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0;
     constexpr uint32_t WIN = (K + 2) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n;
     static_assert(3 * n <= G * COLS && THREADS <= 1024, "lane map");
-    static_assert((n * sizeof(T)) % 16 == 0 && (COLS * sizeof(T)) % 16 == 0, "operand runs start on 16-byte boundaries");
 
     __shared__ __attribute__((aligned(16))) T rwin[WINP], pwin[WINP], swin[WINP], uwin[WINP], wwin[WINP], lwin[WINP];
     __shared__ __attribute__((aligned(16))) T lam[OWN];
@@ -563,7 +569,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
     // publishing wave and the polling wave take over.
 #define GBDPCG_1R_PRODUCT(MREG, XWIN, YWIN, D1, D2, INIT)                                                        \
     {                                                                                                             \
-        T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768)>(MREG, (XWIN) + slot * n + cbase, (XWIN) + slot * n + cbase, T(0))); \
+        T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(MREG, (XWIN) + slot * n + cbase, (XWIN) + slot * n + cbase, T(0))); \
         T d1 = T(0), d2 = T(0);                                                                                   \
         if (g == 0 && row_live) {                                                                                 \
             if (INIT) y = (knot_live ? gamma[k * n + row] : T(0)) - y;                                            \
@@ -696,7 +702,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 
-#define GBDPCG_PERSIST_N(X) X(36)
+#define GBDPCG_PERSIST_N(X) X(14) X(36)
 
 template <typename T> static bool persist_has_kernel(uint32_t n)
 {

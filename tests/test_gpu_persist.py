@@ -169,3 +169,27 @@ def test_single_reduction_iteration_edges(solver, orc, tol, max_iter):
 
 def test_auto_never_takes_the_single_reduction_form(solver):
     assert solver.choose_path(8, 36, 256, 1) == binding.PATH_PERSISTENT
+
+
+# ---- other block sizes: n = 14 (rows of 56 bytes in fp32: the element-wise operand path) -------------------------------
+@pytest.mark.parametrize("path", [P, P1R], ids=["two-reductions", "one-reduction"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(256, 1), (200, 1), (129, 2), (33, 3), (2, 1)])
+def test_persistent_state_size_14(solver, orc, path, dtype, N, B):
+    """Long horizons of the iiwa shape (stateSize 14): one problem of N = 256 knots would stream 1.2 MB per iteration
+    through one CU on the fused path; the persistent launch keeps it in the registers of 128 CUs."""
+    n = 14
+    d = synth.gen_numpy(n, N, seed=700 + N, batch=B, dtype=dtype)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], path=path)
+    assert np.array_equal(out["iters"], ob["iters"].astype(np.int64)), (out["iters"], ob["iters"])
+    assert not out["flag"].any()
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < (1e-10 if dtype == np.float64 else 1e-6)
+
+
+def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
+    assert solver.choose_path(4, 14, 256, 1) == binding.PATH_PERSISTENT      # 1.2 MB per iteration through one CU otherwise
+    assert solver.choose_path(4, 14, 128, 1) == binding.PATH_FUSED           # symmetric halves resident on one CU (default mode 2)
+    assert solver.choose_path(4, 14, 64, 1) == binding.PATH_FUSED            # register-resident
+    assert solver.choose_path(4, 14, 256, 64) == binding.PATH_FUSED or solver.choose_path(4, 14, 256, 64) == binding.PATH_SPLIT
