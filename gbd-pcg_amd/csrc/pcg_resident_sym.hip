@@ -575,6 +575,10 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         }
         __syncthreads();  // LDS (tile, vectors) is reused by the next problem
     }
+    // The prefetch loads are invisible to the compiler's counters; s_endpgm drains the wave's memory counters in
+    // hardware, and this makes it explicit: none of them can still be in flight (towards this workgroup's LDS dump
+    // area) when the workgroup's LDS is handed to another one.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // n = 14, fp32, N <= 128, a preconditioner given, matrices 8-byte aligned.  GBDPCG_NO_RESIDENT_SYM

@@ -708,7 +708,16 @@ def test_randomized_dispatch_sweep(solver, orc, case):
     # iterates drift apart by far more than an ulp (order-sensitive), so those cases only have to
     # exit within three iterations of the oracle, at a point as close to the dense solve as the exit rule implies.
     long_run = pinv is None and not fixed
-    assert np.abs(out["iters"] - ob["iters"].astype(np.int64)).max() <= (3 if long_run else 0)
+    if long_run:
+        # ... and the band is the oracle's own: its four summation-order variants (FMA on / off x tree / sequential
+        # reduce) bracket the exit iteration; the GPU count has to lie within that band widened by two
+        band = np.stack([orc.pcg_batch(n, N, B, S, P_h, g, tol=tol, max_iter=max_iter, flags=f)["iters"].astype(np.int64)
+                         for f in range(4)])
+        gi = out["iters"].astype(np.int64)
+        assert (gi >= band.min(axis=0) - 2).all() and (gi <= band.max(axis=0) + 2).all(), (gi, band)
+        assert np.abs(gi - ob["iters"].astype(np.int64)).max() <= 3
+    else:
+        assert np.array_equal(out["iters"], ob["iters"].astype(np.int64))
     for b in range(B):
         if not np.isfinite(ob["lambda_"][b]).all():
             # fixed iteration count past an exact solve (N = 1 with an exact preconditioner): 0 / 0 in pcg.cuh:169
