@@ -740,9 +740,15 @@ template <typename T, int NCT, int K>
 static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction)
 {
     const uint32_t W = (a.N + K - 1) / K;
-    // ~1 us per failed pass: a launch whose workgroups are not all resident gives up after about two seconds
-    const uint32_t spin_limit = 1u << 21;
-    const dim3 grid(W * a.batch), block(K * PersistGeom<T, NCT>::TPK);
+    // ~1 us per failed pass: a launch whose workgroups are not all resident gives up after about two seconds.
+    // GBDPCG_PERSIST_SPIN_LIMIT / GBDPCG_PERSIST_DROP_WG exist for tests/test_gpu_persist.py only: a short bound, and
+    // a launch that is missing its last workgroup, to drive the give-up path.
+    static const uint32_t spin_limit = [] {
+        const char *e = getenv("GBDPCG_PERSIST_SPIN_LIMIT");
+        return e ? (uint32_t)atoi(e) : (1u << 21);
+    }();
+    static const uint32_t drop = getenv("GBDPCG_PERSIST_DROP_WG") ? 1u : 0u;
+    const dim3 grid(W * a.batch - (W * a.batch > 1 ? drop : 0u)), block(K * PersistGeom<T, NCT>::TPK);
     u64 *ws = reinterpret_cast<u64 *>(workspace);
     if (one_reduction) {
         if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);

@@ -193,3 +193,39 @@ def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
     assert solver.choose_path(4, 14, 128, 1) == binding.PATH_FUSED           # symmetric halves resident on one CU (default mode 2)
     assert solver.choose_path(4, 14, 64, 1) == binding.PATH_FUSED            # register-resident
     assert solver.choose_path(4, 14, 256, 64) == binding.PATH_FUSED or solver.choose_path(4, 14, 256, 64) == binding.PATH_SPLIT
+
+
+_GIVE_UP = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from gbd_pcg_amd import binding, synth
+s = binding.Solver(0)
+s.set_path(binding.PATH_PERSISTENT if sys.argv[2] == "2r" else binding.PATH_PERSISTENT_1R)
+n, N = 36, 64
+d = synth.gen_numpy(n, N, seed=5, batch=1, dtype=np.float64)
+S, P, g = (torch.from_numpy(d[k]).cuda() for k in ("S", "Pinv", "gamma"))
+lam = torch.zeros_like(g)
+it, fl = s.solve(n, N, 1, S, P, g, lam, tol=1e-6, max_iter=30)
+torch.cuda.synchronize()
+print("RESULT", int(it.cpu().numpy().astype(np.uint32)[0]), int(fl[0]))
+"""
+
+
+@pytest.mark.parametrize("form", ["2r", "1r"])
+def test_persistent_launch_gives_up_instead_of_hanging(form):
+    """A persistent launch whose workgroups are not all there (here: the last one is never launched,
+    GBDPCG_PERSIST_DROP_WG, with a short spin bound) must end by itself and say so: d_iters = 0xffffffff,
+    d_max_iter_exit = 2 (include/gbdpcg.h, GBDPCG_PATH_PERSISTENT).  The same process without the test hooks solves."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GBDPCG_PERSIST_DROP_WG="1", GBDPCG_PERSIST_SPIN_LIMIT="2000")
+    out = subprocess.run([sys.executable, "-c", _GIVE_UP, root, form], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    assert int(line[1]) == 0xffffffff and int(line[2]) == 2, line
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GBDPCG_PERSIST_")}
+    out = subprocess.run([sys.executable, "-c", _GIVE_UP, root, form], env=env, capture_output=True, text=True, timeout=120)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    assert 5 <= int(line[1]) <= 15 and int(line[2]) == 0, line
