@@ -85,6 +85,34 @@ def main():
         short = name.split("(")[0].replace("void gbdpcg::", "").replace(" ", "")
         out["kernels"][short] = rec
     json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_sq.json"), "w"), indent=1)
+    # per-config table
+    cj = os.path.join(src, "configs.jsonl")
+    if os.path.exists(cj):
+        lines = ["# gbd-pcg_amd/tools/bench_configs.py on one MI355X: every single-GPU BASELINE config and every path that can run it,",
+                 "# hipGraph replay, median of 50 replays (each replay = lambda.zero_() + graph launch, event-timed, so ~10 us of launch",
+                 "# path is inside).  fixed5 / fixed25 = exit_tol 0 with 5 / 25 iterations, tol1e-6 = converge; us/iter = (fixed25 - fixed5) / 20",
+                 "# = the cost of one more real iteration.  C2 = n14 N64 fp32 x1, C3 = n14 N128 fp32 x1024, C4 = n36 N256 fp64 x1,",
+                 "# C2x64 / C4x16 = small batches, C5on1 = config 5's 8192 problems on one GPU; persist = one persistent launch,",
+                 "# persist1r = its opt-in single-reduction form.  GB/s algorithmic = SURVEY 8d full-storage bytes / time."]
+        recs = [json.loads(ln) for ln in open(cj) if ln.startswith("{")]
+        by = collections.OrderedDict()
+        for r in recs:
+            by.setdefault((r["config"], r.get("path", "spmv")), {})[r["run"]] = r
+        for (cfg, path), runs in by.items():
+            if path == "spmv":
+                r = runs["spmv"]
+                lines.append(f"{cfg:6s} spmv                 {r['ms_median'] * 1e3:9.1f} us   {r['algorithmic_GBps']:8.0f} GB/s algorithmic")
+                continue
+            t5, t25, tc = runs.get("fixed5"), runs.get("fixed25"), runs.get("tol1e-6")
+            if not (t5 and t25 and tc):
+                continue
+            per = (t25["ms_median"] - t5["ms_median"]) * 1e3 / 20.0
+            lines.append(f"{cfg:6s} {path:10s} fixed25 {t25['ms_median'] * 1e3:9.1f} us  converged {tc['ms_median'] * 1e3:9.1f} us ({tc['iters_mean']:.1f} it)  "
+                         f"{per:8.2f} us/iter  {t25['problem_iters_per_s']:.3e} problem-iter/s  {t25['algorithmic_GBps']:7.0f} GB/s algorithmic")
+        open(os.path.join(dst, f"{rnd}_configs.txt"), "w").write("\n".join(lines) + "\n")
+    for name in ("counter_fit.txt", "persist_stamps.txt"):
+        if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
+            open(os.path.join(dst, f"{rnd}_{name}"), "w").write(open(os.path.join(src, name)).read())
     if os.path.exists(os.path.join(src, "bw_probe.txt")):
         open(os.path.join(dst, f"{rnd}_bw_probe.txt"), "w").write(open(os.path.join(src, "bw_probe.txt")).read())
     print("digested", src, "->", dst)

@@ -26,6 +26,16 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES
     -d $OUT/sq -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/sq.log 2>&1 || { tail -5 $OUT/sq.log; exit 1; }
 echo "[6/6] FETCH_SIZE calibration (bw_probe)"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/cal -- $ROOT/gbd-pcg_amd/tools/bw_probe > $OUT/bw_probe.txt 2> $OUT/cal.log || { tail -5 $OUT/cal.log; exit 1; }
+echo "[7] every single-GPU config, all paths (bench_configs.py)"
+python3 $ROOT/gbd-pcg_amd/tools/bench_configs.py --reps 50 > $OUT/configs.jsonl 2> $OUT/configs.err || { tail -5 $OUT/configs.err; exit 1; }
+echo "[8] per-iteration SQ counters of the resident kernel (counter_fit.py)"
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
+    -d $OUT/cfit -- python3 $ROOT/gbd-pcg_amd/tools/counter_fit.py run > $OUT/cfit.log 2>&1 || { tail -5 $OUT/cfit.log; exit 1; }
+python3 $ROOT/gbd-pcg_amd/tools/counter_fit.py digest $OUT/cfit > $OUT/counter_fit.txt
+echo "[9] phase stamps of the persistent kernel (diagnostic build, if present)"
+if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_stamps.so ]; then
+  GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_stamps.so python3 $ROOT/gbd-pcg_amd/tools/persist_stamps.py > $OUT/persist_stamps.txt 2>/dev/null || true
+fi
 # keep what the digest needs, drop the bulky traces
 find $OUT -name "*.db" -delete 2>/dev/null
 du -sh $OUT
