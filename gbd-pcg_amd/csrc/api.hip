@@ -30,9 +30,16 @@ struct gbdpcg_context {
     // split-path workspace, grown on demand outside capture
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    // persistent path: hand-off slots and epoch bases, zero-filled when (re)allocated, grown outside capture
-    void *pws = nullptr;
-    size_t pws_bytes = 0;
+    // persistent path: hand-off slots and epoch bases.  One zero-filled buffer PER SHAPE (element size, n, N, batch), made
+    // outside capture on first use and kept until the handle goes: the slot layout depends on the shape, and a buffer
+    // that only ever sees one layout can never show a launch a stale tag left by another (graphs captured for a shape
+    // keep pointing at that shape's buffer).
+    struct PersistWs {
+        uint64_t key;
+        void *buf;
+    };
+    std::vector<PersistWs> pws;
+    void *pws_last = nullptr;   // diagnostic builds only (gbdpcg_internal_persist_ws)
     // Buffers replaced by a larger one.  Graphs built earlier (gbdpcg_graph_create_solve_*, or a caller's own
     // capture of gbdpcg_solve_*) hold the OLD pointers in their kernel nodes, so growth never frees: the old
     // buffer stays valid until the handle goes.  Sizes at least double, which bounds the total at 2x the largest.
@@ -180,15 +187,39 @@ gbdpcg_status grow_buffer(gbdpcg_handle_t h, void **buf, size_t *cap, size_t nee
 
 gbdpcg_status ensure_ws(gbdpcg_handle_t h, size_t bytes) { return grow_buffer(h, &h->ws, &h->ws_bytes, bytes); }
 
-// The persistent path's workspace must read zero where it was never written (epoch bases, tags): fill after growth.
-gbdpcg_status ensure_pws(gbdpcg_handle_t h, size_t bytes)
+// The persistent path's workspace of one shape (see gbdpcg_context::pws): found, or -- outside capture only -- allocated
+// and zero-filled (epoch bases and tags must read zero where nothing was ever written).
+gbdpcg_status get_pws(gbdpcg_handle_t h, uint32_t elem, uint32_t n, uint32_t N, uint32_t batch, size_t bytes, bool may_allocate,
+                      void **out)
 {
-    if (bytes <= h->pws_bytes) return GBDPCG_OK;
-    gbdpcg_status st = grow_buffer(h, &h->pws, &h->pws_bytes, bytes);
-    if (st != GBDPCG_OK) return st;
-    hipError_t e = hipMemset(h->pws, 0, h->pws_bytes);
+    const uint64_t key = ((uint64_t)elem << 60) ^ ((uint64_t)n << 48) ^ ((uint64_t)N << 24) ^ (uint64_t)batch;
+    for (const auto &e : h->pws)
+        if (e.key == key) {
+            *out = h->pws_last = e.buf;
+            return GBDPCG_OK;
+        }
+    if (!may_allocate) return GBDPCG_ERR_ALLOC;
+    void *buf = nullptr;
+    hipError_t e = hipMalloc(&buf, bytes);
+    if (e != hipSuccess) {
+        h->last_err = e;
+        return GBDPCG_ERR_ALLOC;
+    }
+    e = hipMemset(buf, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    return e == hipSuccess ? GBDPCG_OK : fail(h, e);
+    if (e == hipSuccess) {
+        try {
+            h->pws.push_back({key, buf});
+        } catch (const std::bad_alloc &) {
+            e = hipErrorOutOfMemory;
+        }
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        return fail(h, e);
+    }
+    *out = h->pws_last = buf;
+    return GBDPCG_OK;
 }
 
 gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
@@ -208,14 +239,12 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     DEVICE_SCOPE(h);
     const gbdpcg_path path = pick_path<T>(h, n, N, batch);
     if (path == GBDPCG_PATH_PERSISTENT || path == GBDPCG_PATH_PERSISTENT_1R) {
-        const size_t need = persist_workspace_bytes<T>(n, N, batch);
-        if (need > h->pws_bytes) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GBDPCG_ERR_ALLOC;
-            gbdpcg_status st = ensure_pws(h, need);
-            if (st != GBDPCG_OK) return st;
-        }
-        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, h->pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        void *pws = nullptr;
+        gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_workspace_bytes<T>(n, N, batch), !capturing, &pws);
+        if (st != GBDPCG_OK) return st;   // capturing a shape this handle has not seen: gbdpcg_reserve first
+        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
     } else if (path == GBDPCG_PATH_FUSED) {
         const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
         if (has_sym && h->symmetric == 2 && given_verdict_stride) {
@@ -411,7 +440,8 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     if (!shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     DEVICE_SCOPE(h);
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT || pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT_1R) {
-        gbdpcg_status st = ensure_pws(h, persist_workspace_bytes<T>(n, N, batch));
+        void *pws = nullptr;
+        gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_workspace_bytes<T>(n, N, batch), true, &pws);
         if (st != GBDPCG_OK) return st;
     } else if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
@@ -534,7 +564,7 @@ gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
     if (!h) return GBDPCG_ERR_INVALID;
     DeviceScope scope(h->dev.device);
     if (h->ws) (void)hipFree(h->ws);
-    if (h->pws) (void)hipFree(h->pws);
+    for (const auto &e : h->pws) (void)hipFree(e.buf);
     if (h->sym_flags) (void)hipFree(h->sym_flags);
     for (void *old : h->retired) (void)hipFree(old);
     if (h->d_iters) (void)hipFree(h->d_iters);
@@ -654,7 +684,10 @@ gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, 
     gbdpcg_status st = ensure_sym_flags(h, elem_size == 8 ? verdict_bytes<double>(n, N, batch) : verdict_bytes<float>(n, N, batch));
     if (st != GBDPCG_OK) return st;
     const gbdpcg_path p = elem_size == 8 ? pick_path<double>(h, n, N, batch) : pick_path<float>(h, n, N, batch);
-    if (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) return ensure_pws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
+    if (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) {
+        void *pws = nullptr;
+        return get_pws(h, elem_size, n, N, batch, gbdpcg_workspace_bytes(h, elem_size, n, N, batch), true, &pws);
+    }
     return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
 }
 
@@ -822,7 +855,7 @@ const char *gbdpcg_version(void) { return "gbdpcg 0.1 gfx950"; }
 
 #ifdef GBDPCG_PERSIST_STAMPS
 // diagnostic build only (tools/persist_stamps.py): where the persistent path keeps its stamps
-void *gbdpcg_internal_persist_ws(gbdpcg_handle_t h) { return h ? h->pws : nullptr; }
+void *gbdpcg_internal_persist_ws(gbdpcg_handle_t h) { return h ? h->pws_last : nullptr; }
 #endif
 
 }  // extern "C"

@@ -136,7 +136,9 @@ gbdpcg_status gbdpcg_check_occupancy(gbdpcg_handle_t h, uint32_t elem_size, uint
  * grows its own workspace (and the verdict bytes of the device symmetry check) on demand outside
  * stream capture; call gbdpcg_reserve first when a solve will be captured into a caller-owned graph.
  * Growth never frees: graphs captured earlier keep the old buffers in their kernel nodes, so a replaced
- * buffer stays allocated until gbdpcg_destroy (sizes at least double, so at most 2x the largest is held). */
+ * buffer stays allocated until gbdpcg_destroy (sizes at least double, so at most 2x the largest is held).
+ * The persistent path keeps one small zero-initialised hand-off workspace per shape it has run (element size, n, N,
+ * batch), created on first use outside capture (or by gbdpcg_reserve) and kept until gbdpcg_destroy. */
 size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
                               uint32_t batch);
 gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,

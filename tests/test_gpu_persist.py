@@ -229,3 +229,42 @@ def test_persistent_launch_gives_up_instead_of_hanging(form):
     out = subprocess.run([sys.executable, "-c", _GIVE_UP, root, form], env=env, capture_output=True, text=True, timeout=120)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
     assert 5 <= int(line[1]) <= 15 and int(line[2]) == 0, line
+
+
+def test_alternating_shapes_on_one_handle(solver, orc):
+    """The persistent path keeps one zero-initialised hand-off workspace per shape (the slot layout depends on the
+    shape): solves of different shapes interleaved on one handle, eager and from a graph captured earlier, all stay
+    correct and bit-reproducible."""
+    shapes = [(36, 256, 1, np.float64), (14, 200, 1, np.float32), (36, 100, 2, np.float64), (14, 140, 1, np.float64)]
+    data, first = {}, {}
+    for sh in shapes:
+        n, N, B, dt = sh
+        d = synth.gen_numpy(n, N, seed=900 + N, batch=B, dtype=dt)
+        data[sh] = (d, orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=60))
+    # a graph for the first shape, captured before the others are ever used
+    n, N, B, dt = shapes[0]
+    d0 = data[shapes[0]][0]
+    solver.set_path(P)
+    dS, dP, dg = dev(d0["S"]), dev(d0["Pinv"]), dev(d0["gamma"])
+    glam = torch.zeros_like(dg)
+    git = torch.zeros(B, dtype=torch.int32, device="cuda")
+    gfl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    gr = solver.graph_solve(n, N, B, dS, dP, dg, glam, None, None, 1e-6, 60, git, gfl)
+    solver.set_path(binding.PATH_AUTO)
+    for rnd in range(3):
+        for sh in shapes:
+            n, N, B, dt = sh
+            d, ob = data[sh]
+            out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], max_iter=60)
+            assert np.array_equal(out["iters"], ob["iters"].astype(np.int64)) and not out["flag"].any(), (sh, rnd)
+            for b in range(B):
+                assert relerr(out["lambda_"][b], ob["lambda_"][b]) < (1e-10 if dt == np.float64 else 1e-6)
+            if sh in first:
+                assert np.array_equal(out["lambda_"], first[sh]), (sh, rnd)     # bit-identical run to run
+            first.setdefault(sh, out["lambda_"])
+        glam.zero_()
+        gr.launch()
+        torch.cuda.synchronize()
+        assert int(git[0]) == int(data[shapes[0]][1]["iters"][0]) and int(gfl[0]) == 0
+        assert np.array_equal(glam.cpu().numpy().reshape(1, -1), first[shapes[0]])
+    gr.close()
