@@ -209,3 +209,28 @@ def test_multi_device_cpp_driver():
     res = subprocess.run([exe, "600", "128", "2", "1"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "RCCL ranks = 1" in res.stdout and "problems solved = 600 of 600" in res.stdout
+
+
+def test_bench_line_contract():
+    """`python bench.py` (the driver's command, N = 1): one JSON line with the metric of BASELINE.json, a roofline block
+    whose fraction is a fraction, the SpMV block over the 1.23 GB rotation, the per-config block and the CPU baseline."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3"],
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert rec["metric"] == base["metric"] and rec["unit"] == "iter/s" and rec["n_gpus"] == 1
+    assert rec["steps"] == 10 and rec["warmup"] == 3 and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    assert rec["dtype"] == "f32" and rec["data"] == "synthetic" and "workload" in rec["config"]
+    assert abs(rec["value"] - 1024 * 25 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    rf = rec["roofline"]
+    assert rf["bound"] in ("hbm", "mfma", "valu") and 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["all_problems_symmetric"] is True and rf["replays"] >= 100
+    sp = rec["spmv"]
+    assert sp["bound"] == "hbm" and 0.5 < sp["frac"] <= 1.0 and "1.23 GB" in sp["rotation"]
+    assert set(rec["configs"]) == {"C2", "C4", "C5_on_one_gpu"} and rec["configs"]["C4"]["path"] == "persistent"
+    assert rec["configs"]["C4"]["iters_converged"] == 10.0 and rec["configs"]["C2"]["iters_converged"] == 9.0
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
