@@ -14,6 +14,7 @@ import torch  # noqa: E402
 from gbd_pcg_amd import binding, synth  # noqa: E402
 
 solver = binding.Solver(0)
+PATHS = {1: 'fused', 2: 'split', 3: 'persistent'}
 for (name, n, N, dt) in [("C2 n=14 N=64 fp32", 14, 64, torch.float32), ("n=14 N=128 fp32", 14, 128, torch.float32),
                          ("C4 n=36 N=256 fp64", 36, 256, torch.float64), ("C1 n=2 N=3 fp64", 2, 3, torch.float64)]:
     g = synth.gen_torch(n, N, 1, "cuda", dt, seed=1234)
@@ -33,7 +34,7 @@ for (name, n, N, dt) in [("C2 n=14 N=64 fp32", 14, 64, torch.float32), ("n=14 N=
         ts.append((time.perf_counter() - t0) * 1e6)
     ts.sort()
     print(f"{name}: solve_blocking wall  median {ts[len(ts)//2]:7.1f} us  p10 {ts[len(ts)//10]:7.1f} us  ({it} iterations, "
-          f"path {'fused' if solver.choose_path(S.element_size(), n, N, 1) == 1 else 'split'})", flush=True)
+          f"path {PATHS.get(solver.choose_path(S.element_size(), n, N, 1))})", flush=True)
 
 # comparison: explicit graph replay + device synchronize, wall clock (config 4)
 n, N, dt = 36, 256, torch.float64
