@@ -128,8 +128,10 @@ template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint3
 {
     const bool fits = fused_fits<T>(h->dev, n, N);
     const bool persist = persist_knots_per_wg<T>(h->dev, n, N, batch) != 0;
+    if (h->forced == GBDPCG_PATH_PERSISTENT_1R && persist_knots_per_wg<T>(h->dev, n, N, batch, true) != 0)
+        return GBDPCG_PATH_PERSISTENT_1R;
     if (h->forced == GBDPCG_PATH_PERSISTENT || h->forced == GBDPCG_PATH_PERSISTENT_1R)
-        return persist ? h->forced : (fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT);
+        return persist ? GBDPCG_PATH_PERSISTENT : (fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT);
     if (h->forced == GBDPCG_PATH_FUSED) return fits ? GBDPCG_PATH_FUSED : GBDPCG_PATH_SPLIT;
     if (h->forced == GBDPCG_PATH_SPLIT) return GBDPCG_PATH_SPLIT;
     // A problem too large for one workgroup: one persistent launch over many CUs when all of its workgroups can be

@@ -102,7 +102,8 @@ hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *wo
 // ---- pcg_persist.hip : one large problem over many CUs in ONE persistent launch (matrices register-resident,
 // in-kernel all-gather of {partial inner product, boundary knots} twice per iteration)
 // Knots per workgroup the launch would use; 0 = the shape cannot run persistently on this device.
-template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
+template <typename T>
+uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, bool one_reduction = false);
 template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
 // workspace: persist_workspace_bytes, ZERO-FILLED once when allocated (epoch bases live there), never cleared again
 template <typename T>

@@ -71,6 +71,20 @@ __device__ __forceinline__ bool slot_load(__amdgpu_buffer_rsrc_t region, uint32_
     return x.y == epoch && x.w == epoch;
 }
 
+// ... and written with ONE sc1 (write-through) buffer store: 288 eight-byte stores from one wave were the longest leg
+// of a hand-off; a 16-byte sc1 store keeps each 8-byte half whole (MI355X_MICROARCH.md, Valid forms, R2).
+__device__ __forceinline__ void slot_store(__amdgpu_buffer_rsrc_t region, uint32_t off, uint32_t epoch, float v)
+{
+    const u32x2 x = {__builtin_bit_cast(uint32_t, v), epoch};
+    __builtin_amdgcn_raw_buffer_store_b64(x, region, (int)off, 0, kAuxSc1);
+}
+__device__ __forceinline__ void slot_store(__amdgpu_buffer_rsrc_t region, uint32_t off, uint32_t epoch, double v)
+{
+    const u64 b = __builtin_bit_cast(u64, v);
+    const u32x4 x = {(uint32_t)b, epoch, (uint32_t)(b >> 32), epoch};
+    __builtin_amdgcn_raw_buffer_store_b128(x, region, (int)off, 0, kAuxSc1);
+}
+
 // Bytes between the partial-product slots of two workgroups.  A slot of its own 128-byte line keeps 8 producers from
 // writing into one line that every consumer polls.
 #ifndef GBDPCG_PERSIST_PSTRIDE
@@ -106,36 +120,70 @@ template <typename T> __host__ __device__ inline size_t persist_words(uint32_t n
 #ifndef GBDPCG_PERSIST_GAP
 #define GBDPCG_PERSIST_GAP 1
 #endif
-template <typename T, int NCT, uint32_t PJ, uint32_t NV>
+template <typename T, int NCT, uint32_t PJ, uint32_t NV, uint32_t HN = NCT>
 __device__ __forceinline__ bool persist_sweep_w(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
                                                 uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit, T (&total)[NV ? NV : 1],
                                                 T *yl, T *yr)
 {
-    // NV values per partial slot, adjacent (0: neighbours only, nothing is summed)
+    // NV values per partial slot, adjacent (0: neighbours only, nothing is summed); HN values per neighbour boundary
     constexpr uint32_t PER = Gran<T>::PER, PSTRIDE = (kPartStrideWords > PER ? kPartStrideWords : PER) * 8;
-    constexpr uint32_t NS = NV ? PJ * NV : 1;
-    static_assert(NCT <= 64, "one halo value per lane");
+    constexpr uint32_t NS = NV ? PJ * NV : 1, HV = (HN + 63) / 64;
     static_assert(NV * PER * 8 <= PSTRIDE, "the values of a slot share its line");
-    T pv[NS], hl = T(0), hr = T(0);
-    bool have[NS], have_l = hl_off < 0 || lane >= (uint32_t)NCT, have_r = hr_off < 0 || lane >= (uint32_t)NCT;
+    T pv[NS], hl[HV], hr[HV];
+    bool have[NS], have_l[HV], have_r[HV];
 #pragma unroll
     for (uint32_t j = 0; j < NS; ++j) {
         pv[j] = T(0);
         have[j] = NV == 0 || lane + 64 * (j / (NV ? NV : 1)) >= W;
     }
-    if (GBDPCG_PERSIST_SLEEP0) __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_SLEEP0);
-    for (uint32_t spins = 0;; ++spins) {
-        bool all = true;
 #pragma unroll
-        for (uint32_t j = 0; j < NS; ++j) {
-            if (!have[j])
-                have[j] = slot_load(region, part_off + (lane + 64 * (j / (NV ? NV : 1))) * PSTRIDE + (j % (NV ? NV : 1)) * PER * 8,
-                                    epoch, pv[j]);
-            all = all && have[j];
+    for (uint32_t v = 0; v < HV; ++v) {
+        hl[v] = hr[v] = T(0);
+        have_l[v] = hl_off < 0 || lane + 64 * v >= HN;
+        have_r[v] = hr_off < 0 || lane + 64 * v >= HN;
+    }
+    if (GBDPCG_PERSIST_SLEEP0) __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_SLEEP0);
+    // Two stages: the partials first (everybody's: the wait proper), the neighbours' boundary knots afterwards (published
+    // at the same time, so normally one pass): the fewer loads are in flight during the wait, the sooner it ends.
+    uint32_t spins = 0;
+#ifdef GBDPCG_PERSIST_TWO_STAGE_ALWAYS
+    constexpr bool TWO_STAGE = NV > 0;
+#else
+    constexpr bool TWO_STAGE = NV > 0 && NS + 2 * HV > 4;
+#endif   // few loads per lane: one stage is as fast (measured, config 4)
+    if constexpr (TWO_STAGE) {
+        for (;; ++spins) {
+            bool all = true;
+#pragma unroll
+            for (uint32_t j = 0; j < NS; ++j) {
+                if (!have[j])
+                    have[j] = slot_load(region, part_off + (lane + 64 * (j / (NV ? NV : 1))) * PSTRIDE + (j % (NV ? NV : 1)) * PER * 8,
+                                        epoch, pv[j]);
+                all = all && have[j];
+            }
+            if (__all(all)) break;
+            if (spins >= spin_limit) return false;
+            __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_GAP);
         }
-        if (!have_l) have_l = slot_load(region, (uint32_t)hl_off + lane * PER * 8, epoch, hl);
-        if (!have_r) have_r = slot_load(region, (uint32_t)hr_off + lane * PER * 8, epoch, hr);
-        if (__all(all && have_l && have_r)) break;
+    }
+    for (;; ++spins) {
+        bool all = true;
+        if constexpr (NV > 0 && !TWO_STAGE) {
+#pragma unroll
+            for (uint32_t j = 0; j < NS; ++j) {
+                if (!have[j])
+                    have[j] = slot_load(region, part_off + (lane + 64 * (j / (NV ? NV : 1))) * PSTRIDE + (j % (NV ? NV : 1)) * PER * 8,
+                                        epoch, pv[j]);
+                all = all && have[j];
+            }
+        }
+#pragma unroll
+        for (uint32_t v = 0; v < HV; ++v) {
+            if (!have_l[v]) have_l[v] = slot_load(region, (uint32_t)hl_off + (lane + 64 * v) * PER * 8, epoch, hl[v]);
+            if (!have_r[v]) have_r[v] = slot_load(region, (uint32_t)hr_off + (lane + 64 * v) * PER * 8, epoch, hr[v]);
+            all = all && have_l[v] && have_r[v];
+        }
+        if (__all(all)) break;
         if (spins >= spin_limit) return false;
         __builtin_amdgcn_s_sleep(GBDPCG_PERSIST_GAP);
     }
@@ -148,21 +196,23 @@ __device__ __forceinline__ bool persist_sweep_w(__amdgpu_buffer_rsrc_t region, u
             total[v] = wave_sum(sum);
         }
     }
-    if (lane < (uint32_t)NCT) {
-        yl[lane] = hl;
-        yr[lane] = hr;
-    }
+#pragma unroll
+    for (uint32_t v = 0; v < HV; ++v)
+        if (lane + 64 * v < HN) {
+            yl[lane + 64 * v] = hl[v];
+            yr[lane + 64 * v] = hr[v];
+        }
     return true;
 }
 // partial slots per lane by workgroup count: the sums of the three forms differ only in how many zeros they add
-template <typename T, int NCT, uint32_t NV>
+template <typename T, int NCT, uint32_t NV, uint32_t HN = NCT>
 __device__ __forceinline__ bool persist_sweep_n(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
                                                 uint32_t W, uint32_t epoch, uint32_t lane, uint32_t spin_limit,
                                                 T (&total)[NV ? NV : 1], T *yl, T *yr)
 {
-    if (NV == 0 || W <= 64) return persist_sweep_w<T, NCT, 1, NV>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
-    if (W <= 128) return persist_sweep_w<T, NCT, 2, NV>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
-    return persist_sweep_w<T, NCT, 4, NV>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    if (NV == 0 || W <= 64) return persist_sweep_w<T, NCT, 1, NV, HN>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    if (W <= 128) return persist_sweep_w<T, NCT, 2, NV, HN>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
+    return persist_sweep_w<T, NCT, 4, NV, HN>(region, part_off, hl_off, hr_off, W, epoch, lane, spin_limit, total, yl, yr);
 }
 template <typename T, int NCT>
 __device__ __forceinline__ bool persist_sweep(__amdgpu_buffer_rsrc_t region, uint32_t part_off, int hl_off, int hr_off,
@@ -227,9 +277,13 @@ enum PersistPhase { PP_INIT = 0, PP_PRECOND = 1, PP_DIRECTION = 2 };
     if ((COND) && lane == 0) ws[IDX] = __builtin_amdgcn_s_memtime();
 #define GBDPCG_STAMP_RT(IDX, COND)                                                                \
     if ((COND) && lane == 0) ws[IDX] = __builtin_amdgcn_s_memrealtime();
+// every workgroup's 100 MHz real-time clock at its publish (0) and at the end of its sweep (1), into the second halo region
+#define GBDPCG_XSTAMP(WHICH, COND)                                                                \
+    if ((COND) && lane == 0) (part + persist_part_words<T>(N) + persist_halo_words<T>(n, N))[2 * w + (WHICH)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GBDPCG_STAMP(IDX, COND)
 #define GBDPCG_STAMP_RT(IDX, COND)
+#define GBDPCG_XSTAMP(WHICH, COND)
 #endif
 
 // Lane map of one knot: aligned groups of 8 lanes share a row, lane g of the group holds columns [g*COLS, (g+1)*COLS) of
@@ -250,7 +304,8 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
 {
     using Gm = PersistGeom<T, NCT>;
     constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
-    constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0;   // PUB: the publishing wave
+    // PUB publishes the partial, HPUB the boundary knots (no global store by the polling wave 0 when there are others)
+    constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0, HPUB = NWAVES > 2 ? 2 : PUB;
     constexpr uint32_t WIN = (K + 2) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n;
     static_assert(3 * n <= G * COLS && THREADS <= 1024, "lane map");
 
@@ -289,7 +344,6 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
     u64 *ws = ws_all + (size_t)prob * persist_words<T>(n, N);
     constexpr uint32_t PSW = kPartStrideWords > PER ? kPartStrideWords : PER;   // u64 words per partial slot
     u64 *part = ws + kPersistCtrl;                              // [2][N] slots
-    u64 *halo = part + persist_part_words<T>(N);                // [2][N][2][n] values
     // the same words as a buffer resource for the polling loads (byte offsets from `part`)
     const __amdgpu_buffer_rsrc_t region = __builtin_amdgcn_make_buffer_rsrc(
         part, 0, (int)((persist_words<T>(n, N) - kPersistCtrl) * 8), 0x00020000);
@@ -381,15 +435,18 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
         GBDPCG_STAMP(sb + 1, stamp_here)                                                                             \
         /* No global store is issued before the barrier above (it would make every wave wait for the write-through  \
            acknowledgement), and none by the polling wave (its loads would queue behind them): wave PUB publishes. */  \
-        if (wave == PUB) {                                                                                           \
-            u64 *my_halo = halo + (((size_t)par * N + w) * 2) * n * PER;                                             \
-            for (uint32_t i = lane; i < 2 * n; i += 64) {   /* first knot -> left neighbour, last knot -> right */     \
-                const uint32_t src = i < n ? n + i : n + (K - 1) * n + (i - n);                                       \
-                gran_store(my_halo + (size_t)i * PER, tag, (YWIN)[src]);                                             \
-            }                                                                                                        \
+        if (wave == PUB) {   /* the partial first: every workgroup waits for it, the boundary knots concern two */   \
             T dot = dots[0];                                                                                         \
             _Pragma("unroll") for (uint32_t q = 1; q < NWAVES; ++q) dot += dots[q];                                 \
-            if (lane == 0) gran_store(part + ((size_t)par * N + w) * PSW, tag, dot);                                 \
+            GBDPCG_XSTAMP(0, PHASE == PP_DIRECTION && (ITER) == 3)                                                   \
+            if (lane == 0) slot_store(region, (par * N + w) * PSW * 8u, tag, dot);                                   \
+        }                                                                                                            \
+        if (wave == HPUB) {                                                                                          \
+            const uint32_t my_halo = halo_base + ((par * N + w) * 2) * n * PER * 8u;                                 \
+            for (uint32_t i = lane; i < 2 * n; i += 64) {   /* first knot -> left neighbour, last knot -> right */     \
+                const uint32_t src = i < n ? n + i : n + (K - 1) * n + (i - n);                                       \
+                slot_store(region, my_halo + i * PER * 8u, tag, (YWIN)[src]);                                        \
+            }                                                                                                        \
         }                                                                                                            \
         if (wave == 0) {                                                                                             \
             GBDPCG_STAMP(sb + 2, stamp_here)                                                                         \
@@ -400,6 +457,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
                 w + 1 < W ? (int)(halo_base + ((par * N + (w + 1)) * 2) * n * PER * 8u) : -1, W, tag, lane,          \
                 spin_limit, total, (YWIN), (YWIN) + n + OWN);                                                        \
             GBDPCG_STAMP(sb + 3, stamp_here)                                                                         \
+            GBDPCG_XSTAMP(1, PHASE == PP_DIRECTION && (ITER) == 3)                                                   \
             if (lane == 0) {                                                                                         \
                 if (!ok) {                                                                                           \
                     bci[0] = 2u;                                                                                     \
@@ -466,28 +524,36 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
 }
 
 // ---- single-reduction variant (opt-in: GBDPCG_PATH_PERSISTENT_1R) ------------------------------------------------------
-// The same solve in the Chronopoulos-Gear form of preconditioned CG: u = Pinv r, w = S u, and BOTH inner products
-// gamma = r.u, delta = u.w travel in ONE all-gather per iteration (the north star's "single cross-CU reduction per
-// iteration"); the boundary knots of u go to the two neighbours only (no all-to-all) before w can be formed:
-//     beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)        (beta = 0, alpha = gamma / delta first)
+// The same solve in the Chronopoulos-Gear form of preconditioned CG, arranged so that an iteration crosses the chip
+// ONCE (the north star's "single cross-CU reduction per iteration"):
+//     u = Pinv r ; w = S u ; gamma = r.u ; delta = u.w                      (both inner products in ONE all-gather)
+//     beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)      (beta = 0, alpha = gamma / delta first)
 //     p = u + beta p ; s = w + beta s ; lambda += alpha p ; r -= alpha s
+// w = S u needs u on the two knots next to the workgroup's own.  Instead of a second hand-off they are recomputed here:
+// the workgroup also keeps the Pinv block-rows of those two knots in registers (the threads of its first / last own
+// knot hold one more row run each: +28 VGPRs in fp64) and carries r, s and w on a TWO-knot halo; what travels with the
+// all-gather is {gamma, delta} and the two outer own knots of w on each side.  Redundant values are bit-identical: every
+// copy is the same sequence of fma's on the same bits.
 // In exact arithmetic p, lambda, r and the tested quantity gamma_i = r_i . Pinv r_i are those of pcg.cuh:154-206 (the exit
 // test |gamma| < tol is the same test, seen one product pair later); the ROUNDING sequence differs (alpha is not
-// eta / (p . S p) and s = S p is updated by recurrence), which is why AUTO never picks this kernel: the reference's
-// recurrence stays the default.  Measured against the oracle: equal iteration counts and fp64 lambda within 1e-13 on
-// every shape of tests/test_gpu_persist.py (a = 0.5 and a = 0.9 generators).
+// eta / (p . S p), and s = S p is carried by recurrence), so this is not the reference's recurrence and AUTO does not
+// pick it.  Against the oracle: equal iteration counts and fp64 lambda within 1e-10 on every shape of
+// tests/test_gpu_persist.py (a = 0.5 and a = 0.9 generators).  Two or three knots per workgroup only.
 template <typename T, int NCT, int K, bool HAS_PINV>
 __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_kernel(PcgArgs<T> a, u64 *ws_all, uint32_t W,
                                                                                        uint32_t spin_limit)
 {
     using Gm = PersistGeom<T, NCT>;
+    static_assert(K >= 2, "the first and the last own knot carry one halo block-row each");
     constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
-    constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = NWAVES > 1 ? 1 : 0;
-    constexpr uint32_t WIN = (K + 2) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n;
+    constexpr uint32_t THREADS = K * Gm::TPK, NWAVES = K * WPK, PUB = 1, HPUB = 2, HPUB2 = 3;   // publishing waves
+    static_assert(NWAVES >= 4, "wave 0 polls, three others publish");
+    // windows cover knots k0-2 .. k0+K+1: window knot j = vector knot k0 - 2 + j, own knots are j = 2 .. K+1
+    constexpr uint32_t WIN = (K + 4) * n, WINP = align16<T>(WIN + G * COLS - 3 * n + 1), OWN = K * n, HN = 2 * n;
     static_assert(3 * n <= G * COLS && THREADS <= 1024, "lane map");
 
-    __shared__ __attribute__((aligned(16))) T rwin[WINP], pwin[WINP], swin[WINP], uwin[WINP], wwin[WINP], lwin[WINP];
-    __shared__ __attribute__((aligned(16))) T lam[OWN];
+    __shared__ __attribute__((aligned(16))) T rwin[WINP], swin[WINP], uwin[WINP], wwin[WINP], lwin[WINP];
+    __shared__ __attribute__((aligned(16))) T lam[OWN], pown[OWN];
     __shared__ T dots_g[NWAVES], dots_d[NWAVES];
     __shared__ T bc[4];          // [0] alpha, [1] beta, [2] gamma_old, [3] alpha_old
     __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out, 3 ran out), [1] iterations
@@ -499,12 +565,14 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
     const uint32_t g = lane & 7u, row = wv * 8 + (lane >> 3);
     const bool row_live = row < n;
     const uint32_t cbase = g * COLS;
-    const uint32_t oi = slot * n + (row_live ? row : 0u);
 
     const uint32_t prob = blockIdx.x / W, b = blockIdx.x - prob * W;
     const uint32_t w = (W % 8 == 0) ? (b % 8) * (W / 8) + b / 8 : b;   // neighbours on one XCD (speed only)
     const uint32_t k0 = w * K, k = k0 + slot;
-    const bool knot_live = k < N;
+    // the halo knot whose Pinv block-row this thread carries as well: left of the first own knot / right of the last
+    const bool has_halo = slot == 0 || slot == K - 1;
+    const int64_t kh = slot == 0 ? (int64_t)k0 - 1 : (int64_t)k0 + K;
+    const uint32_t jh = slot == 0 ? 1u : K + 2u;   // its window knot
 
     const size_t mstride = (size_t)3 * n * n * N;
     const T *S = a.S + prob * mstride;
@@ -515,116 +583,133 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
     u64 *ws = ws_all + (size_t)prob * persist_words<T>(n, N);
     constexpr uint32_t PSW = kPartStrideWords > 2 * PER ? kPartStrideWords : 2 * PER;
     static_assert(PSW == kPartStrideWords, "two values per partial slot fit the slot stride");
-    u64 *part = ws + kPersistCtrl;                                   // [2][N] slots of {gamma, delta}
-    u64 *halo_w = part + persist_part_words<T>(N);                   // [2][N][2][n]: boundary knots of r (prologue) and w
-    u64 *halo_u = halo_w + persist_halo_words<T>(n, N);              // [2][N][2][n]: boundary knots of u
+    u64 *part = ws + kPersistCtrl;                       // [2][N] slots of {gamma, delta}
     const __amdgpu_buffer_rsrc_t region = __builtin_amdgcn_make_buffer_rsrc(
         part, 0, (int)((persist_words<T>(n, N) - kPersistCtrl) * 8), 0x00020000);
-    const uint32_t hw_base = (uint32_t)(persist_part_words<T>(N) * 8);
-    const uint32_t hu_base = hw_base + (uint32_t)(persist_halo_words<T>(n, N) * 8);
+    const uint32_t h_base = (uint32_t)(persist_part_words<T>(N) * 8);
     const uint32_t base = (uint32_t)__hip_atomic_load(ws, GBDPCG_RLX_AGENT);
 
-    T sreg[COLS], preg[COLS];
+    // ---- resident block-rows: S and Pinv of the own knot, Pinv of the thread's halo knot ---------------------------
+    T sreg[COLS], preg[COLS], hreg[COLS];
     {
-        const T *Sk = S + (size_t)(knot_live ? k : 0u) * 3 * n * n;
-        const T *Pk = (HAS_PINV ? P : S) + (size_t)(knot_live ? k : 0u) * 3 * n * n;
-        T sraw[COLS], praw[COLS];
+        auto col_ok = [&](int64_t kk, uint32_t c) {   // L_0 and R_{N-1} are never used (pcg.cuh:105-106); knots outside [0, N) are zero
+            return row_live && kk >= 0 && kk < (int64_t)N && c < 3 * n && !(kk == 0 && c < n) && !(kk == (int64_t)N - 1 && c >= 2 * n);
+        };
+        const uint32_t kc = k < N ? k : 0u, khc = (kh >= 0 && kh < (int64_t)N) ? (uint32_t)kh : 0u;
+        const T *Sk = S + (size_t)kc * 3 * n * n;
+        const T *Pk = (HAS_PINV ? P : S) + (size_t)kc * 3 * n * n;
+        const T *Ph = (HAS_PINV ? P : S) + (size_t)khc * 3 * n * n;
+        T sraw[COLS], praw[COLS], hraw[COLS];
 #pragma unroll
         for (uint32_t i = 0; i < COLS; ++i) {
             const uint32_t c = cbase + i;
-            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
-            const uint32_t idx = valid ? c * n + row : n * n;
-            sraw[i] = Sk[idx];
-            if (HAS_PINV) praw[i] = Pk[idx];
+            sraw[i] = Sk[col_ok(k, c) ? c * n + row : n * n];
+            if (HAS_PINV) {
+                praw[i] = Pk[col_ok(k, c) ? c * n + row : n * n];
+                hraw[i] = Ph[(has_halo && col_ok(kh, c)) ? c * n + row : n * n];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (uint32_t i = 0; i < COLS; ++i) {
             const uint32_t c = cbase + i;
-            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
-            sreg[i] = valid ? sraw[i] : T(0);
-            if (HAS_PINV) preg[i] = valid ? praw[i] : T(0);
-            else preg[i] = (valid && c == n + row) ? T(1) : T(0);
+            const bool vk = col_ok(k, c), vh = has_halo && col_ok(kh, c);
+            sreg[i] = vk ? sraw[i] : T(0);
+            if (HAS_PINV) {
+                preg[i] = vk ? praw[i] : T(0);
+                hreg[i] = vh ? hraw[i] : T(0);
+            } else {   // d_Pinv == NULL: identity preconditioner
+                preg[i] = (vk && c == n + row) ? T(1) : T(0);
+                hreg[i] = (vh && c == n + row) ? T(1) : T(0);
+            }
         }
     }
 
     for (uint32_t i = tid; i < WINP; i += THREADS) {
-        rwin[i] = pwin[i] = swin[i] = uwin[i] = wwin[i] = T(0);
-        const int64_t gi = (int64_t)k0 * n - n + i;
+        rwin[i] = swin[i] = uwin[i] = wwin[i] = T(0);
+        const int64_t gi = (int64_t)k0 * n - 2 * (int64_t)n + i;
         lwin[i] = (i < WIN && gi >= 0 && gi < (int64_t)len) ? lambda[gi] : T(0);
     }
-    for (uint32_t i = tid; i < OWN; i += THREADS) lam[i] = (k0 * n + i < len) ? lambda[k0 * n + i] : T(0);
+    for (uint32_t i = tid; i < OWN; i += THREADS) {
+        lam[i] = (k0 * n + i < len) ? lambda[k0 * n + i] : T(0);
+        pown[i] = T(0);
+    }
     if (tid == 0) {
         bc[0] = bc[1] = bc[2] = bc[3] = T(0);
         bci[0] = bci[1] = 0u;
     }
     __syncthreads();
 
-    // hand-off slot offsets (bytes from `part`) of this workgroup's neighbours, by buffer parity
-    auto nbr_l = [&](uint32_t hbase, uint32_t par) { return w > 0 ? (int)(hbase + ((par * N + (w - 1)) * 2 + 1) * n * PER * 8u) : -1; };
-    auto nbr_r = [&](uint32_t hbase, uint32_t par) { return w + 1 < W ? (int)(hbase + ((par * N + (w + 1)) * 2) * n * PER * 8u) : -1; };
-
-    // One product y = M X over the own knots (X a complete window in LDS), y's own part into YWIN, and the workgroup's
-    // shares d1 = sum D1own * y (and d2 = sum D2own * y) into dots_g / dots_d.  Ends with the barrier behind which the
-    // publishing wave and the polling wave take over.
-#define GBDPCG_1R_PRODUCT(MREG, XWIN, YWIN, D1, D2, INIT)                                                        \
-    {                                                                                                             \
-        T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(MREG, (XWIN) + slot * n + cbase, (XWIN) + slot * n + cbase, T(0))); \
-        T d1 = T(0), d2 = T(0);                                                                                   \
-        if (g == 0 && row_live) {                                                                                 \
-            if (INIT) y = (knot_live ? gamma[k * n + row] : T(0)) - y;                                            \
-            (YWIN)[n + oi] = y;                                                                                   \
-            if ((D1) != nullptr) d1 = (D1)[n + oi] * y;                                                           \
-            if ((D2) != nullptr) d2 = (D2)[n + oi] * y;                                                           \
-        }                                                                                                         \
-        d1 = wave_sum(d1);                                                                                        \
-        d2 = wave_sum(d2);                                                                                        \
-        if (lane == 0) {                                                                                          \
-            if ((D1) != nullptr) dots_g[wave] = d1;                                                               \
-            if ((D2) != nullptr) dots_d[wave] = d2;                                                               \
-        }                                                                                                         \
-        __syncthreads();                                                                                          \
-    }
-    // wave PUB: the two boundary knots of YWIN for the neighbours
-#define GBDPCG_1R_PUBLISH_HALO(HALO, YWIN, PAR, TAG)                                                              \
-    {                                                                                                             \
-        u64 *my_halo = (HALO) + (((size_t)(PAR) * N + w) * 2) * n * PER;                                          \
-        for (uint32_t i = lane; i < 2 * n; i += 64) {                                                             \
-            const uint32_t src = i < n ? n + i : n + (K - 1) * n + (i - n);                                        \
-            gran_store(my_halo + (size_t)i * PER, (TAG), (YWIN)[src]);                                            \
-        }                                                                                                         \
+    // hand-off offsets (bytes from `part`): a workgroup publishes [side 0: its first two own knots | side 1: its last two]
+    // hand-off offsets (bytes from `part`): a workgroup publishes [side 0: its first two own knots | side 1: its last two]
+    auto nbr_l = [&](uint32_t par) { return w > 0 ? (int)(h_base + ((par * W + (w - 1)) * 2 + 1) * HN * PER * 8u) : -1; };
+    auto nbr_r = [&](uint32_t par) { return w + 1 < W ? (int)(h_base + ((par * W + (w + 1)) * 2) * HN * PER * 8u) : -1; };
+    // waves HPUB / HPUB2: the two outer own knots of YWIN on the left / right side, for the neighbours' two-knot halo
+#define GBDPCG_1R_PUBLISH_HALO(YWIN, PAR, TAG)                                                                    \
+    if (wave == HPUB || wave == HPUB2) {                                                                          \
+        const uint32_t side = wave == HPUB ? 0u : 1u;                                                             \
+        const uint32_t mh = h_base + (((PAR) * W + w) * 2 + side) * HN * PER * 8u;                                \
+        for (uint32_t i = lane; i < HN; i += 64)                                                                  \
+            slot_store(region, mh + i * PER * 8u, (TAG), (YWIN)[(side ? 2 * n + (K - 2) * n : 2 * n) + i]);       \
     }
 
-    T *const none = nullptr;
-    // r = gamma - S lambda (pcg.cuh:118-126); its boundary knots go to the neighbours with epoch 1
-    GBDPCG_1R_PRODUCT(sreg, lwin, rwin, none, none, true)
-    if (wave == PUB) GBDPCG_1R_PUBLISH_HALO(halo_w, rwin, 1u, base + 1u)
-    if (wave == 0) {
-        T dummy[1];
-        const bool ok = persist_sweep_n<T, NCT, 0>(region, 0u, nbr_l(hw_base, 1u), nbr_r(hw_base, 1u), W, base + 1u, lane, spin_limit,
-                                                   dummy, rwin, rwin + n + OWN);
-        if (lane == 0 && !ok) bci[0] = 2u;
-    }
-    __syncthreads();
-
-    uint32_t iter = 0;
-    for (; bci[0] == 0u; ++iter) {
-        const uint32_t eu = 2u + 2u * iter, ew = 3u + 2u * iter, par = iter & 1u;
-        // u = Pinv r ; share of gamma = r . u ; boundary knots of u to the two neighbours      (pcg.cuh:180-187)
-        GBDPCG_1R_PRODUCT(preg, rwin, uwin, rwin, none, false)
-        if (wave == PUB) GBDPCG_1R_PUBLISH_HALO(halo_u, uwin, par, base + eu)
+    // r = gamma - S lambda (pcg.cuh:118-126) on the own knots; its two outer own knots go to the neighbours (epoch 1)
+    {
+        T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(sreg, lwin + (slot + 1) * n + cbase,
+                                                                               lwin + (slot + 1) * n + cbase, T(0)));
+        if (g == 0 && row_live) rwin[(slot + 2) * n + row] = (k < N ? gamma[k * n + row] : T(0)) - y;
+        __syncthreads();
+        GBDPCG_1R_PUBLISH_HALO(rwin, 1u, base + 1u)
         if (wave == 0) {
             T dummy[1];
-            const bool ok = persist_sweep_n<T, NCT, 0>(region, 0u, nbr_l(hu_base, par), nbr_r(hu_base, par), W, base + eu, lane,
-                                                       spin_limit, dummy, uwin, uwin + n + OWN);
+            const bool ok = persist_sweep_n<T, NCT, 0, HN>(region, 0u, nbr_l(1u), nbr_r(1u), W, base + 1u, lane, spin_limit, dummy,
+                                                          rwin, rwin + (K + 2) * n);
             if (lane == 0 && !ok) bci[0] = 2u;
         }
         __syncthreads();
-        if (bci[0] != 0u) break;
-        // w = S u ; share of delta = u . w ; {gamma, delta, boundary knots of w} in ONE all-gather
-        GBDPCG_1R_PRODUCT(sreg, uwin, wwin, none, uwin, false)
-        if (wave == PUB) {
-            GBDPCG_1R_PUBLISH_HALO(halo_w, wwin, par, base + ew)
+    }
+
+    uint32_t iter = 0;
+    for (; bci[0] == 0u; ++iter) {
+        const uint32_t ew = 2u + iter, par = iter & 1u;
+        const bool stamp_here = w == 1 && wave == 0 && iter == 3;
+        (void)stamp_here;
+        GBDPCG_STAMP(2, stamp_here)
+        // u = Pinv r on the own knots and, redundantly, on the two knots next to them; share of gamma = r . u  (pcg.cuh:180-187)
+        {
+            T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(preg, rwin + (slot + 1) * n + cbase,
+                                                                                   rwin + (slot + 1) * n + cbase, T(0)));
+            T yh = T(0);
+            if (has_halo)   // wave-uniform
+                yh = group_sum8(persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(hreg, rwin + (jh - 1) * n + cbase,
+                                                                                       rwin + (jh - 1) * n + cbase, T(0)));
+            T d = T(0);
+            if (g == 0 && row_live) {
+                uwin[(slot + 2) * n + row] = y;
+                if (has_halo) uwin[jh * n + row] = yh;
+                d = rwin[(slot + 2) * n + row] * y;
+            }
+            d = wave_sum(d);
+            if (lane == 0) dots_g[wave] = d;
+        }
+        __syncthreads();
+        GBDPCG_STAMP(3, stamp_here)
+        // w = S u on the own knots ; share of delta = u . w
+        {
+            T y = group_sum8(persist_row_dot<T, COLS, (THREADS > 768), Gm::ALIGNED>(sreg, uwin + (slot + 1) * n + cbase,
+                                                                                   uwin + (slot + 1) * n + cbase, T(0)));
+            T d = T(0);
+            if (g == 0 && row_live) {
+                wwin[(slot + 2) * n + row] = y;
+                d = uwin[(slot + 2) * n + row] * y;
+            }
+            d = wave_sum(d);
+            if (lane == 0) dots_d[wave] = d;
+        }
+        __syncthreads();
+        GBDPCG_STAMP(4, stamp_here)
+        // {gamma, delta, the two outer own knots of w per side} in ONE all-gather
+        if (wave == PUB) {   // the partials first: every workgroup waits for them
             T pg = dots_g[0], pd = dots_d[0];
 #pragma unroll
             for (uint32_t q = 1; q < NWAVES; ++q) {
@@ -632,15 +717,16 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
                 pd += dots_d[q];
             }
             if (lane == 0) {
-                u64 *slot_p = part + ((size_t)par * N + w) * PSW;
-                gran_store(slot_p, base + ew, pg);
-                gran_store(slot_p + PER, base + ew, pd);
+                slot_store(region, (par * N + w) * PSW * 8u, base + ew, pg);
+                slot_store(region, (par * N + w) * PSW * 8u + PER * 8u, base + ew, pd);
             }
         }
+        GBDPCG_1R_PUBLISH_HALO(wwin, par, base + ew)
         if (wave == 0) {
             T tot[2];
-            const bool ok = persist_sweep_n<T, NCT, 2>(region, par * N * PSW * 8u, nbr_l(hw_base, par), nbr_r(hw_base, par), W, base + ew,
-                                                       lane, spin_limit, tot, wwin, wwin + n + OWN);
+            const bool ok = persist_sweep_n<T, NCT, 2, HN>(region, par * N * PSW * 8u, nbr_l(par), nbr_r(par), W, base + ew, lane,
+                                                          spin_limit, tot, wwin, wwin + (K + 2) * n);
+            GBDPCG_STAMP(5, stamp_here)
             if (lane == 0) {
                 const T gam = tot[0], del = tot[1];
                 if (!ok) {
@@ -663,22 +749,25 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
             }
         }
         __syncthreads();
+        GBDPCG_STAMP(6, stamp_here)
         if (bci[0] != 0u) break;
-        // p = u + beta p ; s = w + beta s ; lambda += alpha p ; r -= alpha s   (own and halo knots: element-wise, in place)
+        // s = w + beta s ; r -= alpha s on the own knots and the two-knot halo ; p = u + beta p ; lambda += alpha p on the own
         {
             const T alpha = bc[0], beta = bc[1];
             for (uint32_t i = tid; i < WIN; i += THREADS) {
-                const T pn = fma_t(beta, pwin[i], uwin[i]);
                 const T sn = fma_t(beta, swin[i], wwin[i]);
-                pwin[i] = pn;
                 swin[i] = sn;
                 rwin[i] = fma_t(-alpha, sn, rwin[i]);
-                if (i >= n && i < n + OWN) lam[i - n] = fma_t(alpha, pn, lam[i - n]);
+                if (i >= 2 * n && i < 2 * n + OWN) {
+                    const T pn = fma_t(beta, pown[i - 2 * n], uwin[i]);
+                    pown[i - 2 * n] = pn;
+                    lam[i - 2 * n] = fma_t(alpha, pn, lam[i - 2 * n]);
+                }
             }
         }
         __syncthreads();
+        GBDPCG_STAMP(7, stamp_here)
     }
-#undef GBDPCG_1R_PRODUCT
 #undef GBDPCG_1R_PUBLISH_HALO
 
     // ---- outputs (pcg.cuh:212,215) --------------------------------------------------------------------------------
@@ -689,8 +778,8 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
         const uint32_t gi = k0 * n + i;
         if (gi < len) {
             lambda[gi] = lam[i];
-            if (a.r) a.r[(size_t)prob * len + gi] = rwin[n + i];
-            if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pwin[n + i], uwin[n + i]) : (bci[1] == 0u && !failed ? uwin[n + i] : pwin[n + i]);
+            if (a.r) a.r[(size_t)prob * len + gi] = rwin[2 * n + i];
+            if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pown[i], uwin[2 * n + i]) : pown[i];
         }
     }
     if (w == 0 && tid == 0) {
@@ -715,7 +804,7 @@ template <typename T> static bool persist_has_kernel(uint32_t n)
 
 // Knots per workgroup for this launch (0: the shape cannot run persistently): every workgroup must be resident at
 // once, one per CU.
-template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch)
+template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, bool one_reduction)
 {
     static const bool off = getenv("GBDPCG_NO_PERSIST") != nullptr;   // tuning runs only
     if (off || !persist_has_kernel<T>(n)) return 0;
@@ -726,6 +815,7 @@ template <typename T> uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint3
     // two knots per workgroup measured fastest on config 4 (5.7 us per iteration; 6.2 with three, 6.9 with one)
     for (uint32_t K : {2u, 3u, 1u}) {
         if (forced && (uint32_t)forced != K) continue;
+        if (one_reduction && K < 2) continue;   // its first and last own knots carry one halo block-row each
         if ((uint64_t)((N + K - 1) / K) * batch <= (uint64_t)dev.num_cus && (N + K - 1) / K <= 256) return K;
     }
     return 0;
@@ -751,8 +841,12 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
     const dim3 grid(W * a.batch - (W * a.batch > 1 ? drop : 0u)), block(K * PersistGeom<T, NCT>::TPK);
     u64 *ws = reinterpret_cast<u64 *>(workspace);
     if (one_reduction) {
-        if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
-        else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
+        if constexpr (K >= 2) {
+            if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
+            else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
+        } else {
+            return hipErrorInvalidValue;
+        }
     } else {
         if (a.Pinv) hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
         else hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
@@ -763,7 +857,7 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
 template <typename T>
 hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction)
 {
-    const uint32_t K = persist_knots_per_wg<T>(dev, a.n, a.N, a.batch);
+    const uint32_t K = persist_knots_per_wg<T>(dev, a.n, a.N, a.batch, one_reduction);
     if (K == 0 || workspace == nullptr) return hipErrorInvalidValue;
 #define GBDPCG_CASE(NN)                                                                       \
     if (a.n == NN) {                                                                          \
@@ -776,8 +870,8 @@ hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *
     return hipErrorInvalidValue;
 }
 
-template uint32_t persist_knots_per_wg<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
-template uint32_t persist_knots_per_wg<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
+template uint32_t persist_knots_per_wg<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, bool);
+template uint32_t persist_knots_per_wg<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, bool);
 template size_t persist_workspace_bytes<float>(uint32_t, uint32_t, uint32_t);
 template size_t persist_workspace_bytes<double>(uint32_t, uint32_t, uint32_t);
 template hipError_t launch_pcg_persist<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t, bool);

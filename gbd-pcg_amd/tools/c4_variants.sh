@@ -8,6 +8,7 @@ for V in ${1:-base}; do for K in ${2:-2 3}; do
 import sys,json
 t={}
 for l in sys.stdin:
-    r=json.loads(l); t[r['run']]=r['ms_median']*1e3
-print('   fixed5 %.1f fixed25 %.1f conv %.1f  => %.2f us/iter' % (t['fixed5'],t['fixed25'],t['tol1e-6'],(t['fixed25']-t['fixed5'])/20))
+    r=json.loads(l); t[(r['path'],r['run'])]=r['ms_median']*1e3
+for p in ('persist','persist1r'):
+    print('   %-9s fixed5 %.1f fixed25 %.1f conv %.1f  => %.2f us/iter' % (p,t[(p,'fixed5')],t[(p,'fixed25')],t[(p,'tol1e-6')],(t[(p,'fixed25')]-t[(p,'fixed5')])/20))
 "; done; done

@@ -19,7 +19,8 @@ from gbd_pcg_amd import binding, synth  # noqa: E402
 def main():
     n, N = 36, 256
     s = binding.Solver(0)
-    s.set_path(binding.PATH_PERSISTENT)
+    one_r = len(sys.argv) > 1 and sys.argv[1] == "1r"
+    s.set_path(binding.PATH_PERSISTENT_1R if one_r else binding.PATH_PERSISTENT)
     g = synth.gen_torch_seeded(n, N, 0, 1, "cuda", torch.float64, seed=1234)
     S, gamma = g["S"], g["gamma"]
     P = s.form_pinv(n, N, 1, S, binding.PINV_STAIR)
@@ -36,6 +37,23 @@ def main():
         hip = ctypes.CDLL("libamdhip64.so")
         assert hip.hipMemcpy(host, ctypes.c_void_p(ptr), 128, 2) == 0
         rows.append(list(host))
+    if one_r:
+        print("single-reduction form, iteration 3, wave 0 of workgroup 1: cycles from the top of the iteration to "
+              "[u done + barrier, w done + barrier, all-gather done, decision + barrier, updates + barrier]")
+        for r in rows[2:]:
+            print("   ", [int(r[i] - r[2]) for i in (3, 4, 5, 6, 7)])
+        return
+    # hop latency: every workgroup's real-time clock (100 MHz, common to the chip) at its publish and at the end of its sweep
+    K = int(os.environ.get("GBDPCG_PERSIST_K", "2"))
+    Wn = (N + K - 1) // K
+    words = 16 + 2 * N * 16 + 2 * N * 2 * n * 2          # ctrl + partial slots (128-byte stride) + first halo region (fp64), in u64
+    xs = (ctypes.c_uint64 * (2 * Wn))()
+    assert hip.hipMemcpy(xs, ctypes.c_void_p(ptr + 8 * words), 8 * 2 * Wn, 2) == 0
+    pub = [xs[2 * i] for i in range(Wn)]
+    det = [xs[2 * i + 1] for i in range(Wn)]
+    last = max(pub)
+    print("hop (iteration 3, S p phase, last solve): publishes spread over %d x 10 ns; sweep ends %d .. %d x 10 ns after the LAST publish "
+          "(median %d)" % (last - min(pub), min(det) - last, max(det) - last, sorted(det)[Wn // 2] - last))
     for tag, b in (("direction (S p)", 2), ("precond (Pinv r)", 8)):
         print(tag, ": cycles from phase start to [product+barrier, reduce+publish, sweep done, barrier]")
         for r in rows[2:]:
