@@ -22,7 +22,7 @@ PINV_IDENTITY, PINV_BLOCK_JACOBI, PINV_STAIR = 0, 1, 2
 # every symbol include/gbdpcg.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "gbdpcg_create", "gbdpcg_destroy", "gbdpcg_status_string", "gbdpcg_last_hip_error",
-    "gbdpcg_last_hip_error_string", "gbdpcg_set_path", "gbdpcg_choose_path", "gbdpcg_set_symmetric",
+    "gbdpcg_last_hip_error_string", "gbdpcg_set_path", "gbdpcg_choose_path", "gbdpcg_cluster_members", "gbdpcg_set_symmetric",
     "gbdpcg_check_symmetric_f32", "gbdpcg_check_symmetric_f64",
     "gbdpcg_pcg_shared_mem_size", "gbdpcg_check_occupancy", "gbdpcg_workspace_bytes",
     "gbdpcg_reserve", "gbdpcg_spmv_f32", "gbdpcg_spmv_f64", "gbdpcg_solve_f32", "gbdpcg_solve_f64",
@@ -131,6 +131,9 @@ class Solver:
     def choose_path(self, elem_size, n, N, batch) -> int:
         return self.lib.gbdpcg_choose_path(self.h, ctypes.c_uint32(elem_size), ctypes.c_uint32(n),
                                            ctypes.c_uint32(N), ctypes.c_uint32(batch))
+
+    def cluster_members(self, elem_size, n, N) -> int:
+        return self.lib.gbdpcg_cluster_members(ctypes.c_uint32(elem_size), ctypes.c_uint32(n), ctypes.c_uint32(N))
 
     def reserve(self, elem_size, n, N, batch):
         self._check(self.lib.gbdpcg_reserve(self.h, ctypes.c_uint32(elem_size), ctypes.c_uint32(n),

@@ -39,6 +39,9 @@ struct gbdpcg_context {
         void *buf;
     };
     std::vector<PersistWs> pws;
+    // cluster path (pcg_cluster.hip): hand-off slots, one per CU and epoch parity.  Made with the handle (its size does not
+    // depend on the shape) and zero-filled once: every launch leaves it zeroed again.
+    void *cluster_ws = nullptr;
     void *pws_last = nullptr;   // diagnostic builds only (gbdpcg_internal_persist_ws)
     // Buffers replaced by a larger one.  Graphs built earlier (gbdpcg_graph_create_solve_*, or a caller's own
     // capture of gbdpcg_solve_*) hold the OLD pointers in their kernel nodes, so growth never frees: the old
@@ -139,13 +142,15 @@ template <typename T> gbdpcg_path pick_path(gbdpcg_handle_t h, uint32_t n, uint3
     if (!fits) return persist ? GBDPCG_PATH_PERSISTENT : GBDPCG_PATH_SPLIT;
     // Fits one workgroup but would stream both matrices through ONE CU's share of the fabric every iteration
     // (43 GB/s measured, below): the persistent launch keeps them in registers and pays ~5.7 us per iteration.
-    if (persist && !resident_shape<T>(n, N) && !(h->symmetric != 0 && resident_sym_shape<T>(n, N)) &&
+    const bool cluster = cluster_members<T>(n, N) != 0;   // general storage resident over 2-4 CUs (pcg_cluster.hip)
+    if (persist && !cluster && !resident_shape<T>(n, N) && !(h->symmetric != 0 && resident_sym_shape<T>(n, N)) &&
         6.0 * n * n * N * sizeof(T) / 43e9 > 6e-6)
         return GBDPCG_PATH_PERSISTENT;
     // Shapes whose matrices stay on the CU for the whole solve: fused, whatever the batch.  (Symmetric mode 2
     // decides per problem on the device; the path is chosen for the problems that pass.)
     if (resident_shape<T>(n, N)) return GBDPCG_PATH_FUSED;
     if (h->symmetric != 0 && resident_sym_shape<T>(n, N)) return GBDPCG_PATH_FUSED;
+    if (cluster) return GBDPCG_PATH_FUSED;
     if (batch >= (uint32_t)h->dev.num_cus) return GBDPCG_PATH_FUSED;  // every CU has a problem of its own to stream
     // Streaming, fewer problems than CUs.  FUSED: one workgroup per problem pulls both matrices through ONE CU's
     // share of the fabric every iteration (43 GB/s measured on the general kernel: 13.9 us per iteration for the
@@ -238,6 +243,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
+    a.cluster_ws = h->cluster_ws;
     DEVICE_SCOPE(h);
     const gbdpcg_path path = pick_path<T>(h, n, N, batch);
     if (path == GBDPCG_PATH_PERSISTENT || path == GBDPCG_PATH_PERSISTENT_1R) {
@@ -248,7 +254,11 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
         if (st != GBDPCG_OK) return st;   // capturing a shape this handle has not seen: gbdpcg_reserve first
         HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
     } else if (path == GBDPCG_PATH_FUSED) {
-        const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && fused_has_symmetric<T>(h->dev, n, N, batch);
+        // shapes the cluster kernel keeps resident in general storage gain nothing from symmetric STREAMING: only the
+        // CU-resident symmetric kernel (N <= 128) is worth a symmetry test there
+        const bool cluster_only = cluster_members<T>(n, N) != 0 && !resident_sym_shape<T>(n, N);
+        const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && !cluster_only &&
+                             fused_has_symmetric<T>(h->dev, n, N, batch);
         if (has_sym && h->symmetric == 2 && given_verdict_stride) {
             // the verdict bytes are already in h->sym_flags, put there on this stream by the stair kernel that just
             // formed Pinv from S (gbdpcg_form_pinv_solve_*): no test launch
@@ -540,6 +550,8 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     DeviceScope scope(device);
     hipError_t e = scope.err;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
+    if (e == hipSuccess) e = hipMalloc(&h->cluster_ws, cluster_workspace_bytes(h->dev));
+    if (e == hipSuccess) e = hipMemset(h->cluster_ws, 0, cluster_workspace_bytes(h->dev));
     if (e == hipSuccess) {
         h->d_exit = reinterpret_cast<uint8_t *>(h->d_iters) + 128;
         // coherent (fine-grained) mapping: the device-side bump of h_done must reach the host while the stream still runs
@@ -547,6 +559,7 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     }
     if (e != hipSuccess) {
         if (h->d_iters) (void)hipFree(h->d_iters);
+        if (h->cluster_ws) (void)hipFree(h->cluster_ws);
         delete h;
         return GBDPCG_ERR_HIP;
     }
@@ -568,6 +581,7 @@ gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
     if (h->ws) (void)hipFree(h->ws);
     for (const auto &e : h->pws) (void)hipFree(e.buf);
     if (h->sym_flags) (void)hipFree(h->sym_flags);
+    if (h->cluster_ws) (void)hipFree(h->cluster_ws);
     for (void *old : h->retired) (void)hipFree(old);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->h_iters) (void)hipHostFree(h->h_iters);
@@ -641,6 +655,12 @@ gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n
 {
     if (!h || !shape_ok(n, N, batch)) return GBDPCG_PATH_AUTO;
     return elem_size == 8 ? pick_path<double>(h, n, N, batch) : pick_path<float>(h, n, N, batch);
+}
+
+uint32_t gbdpcg_cluster_members(uint32_t elem_size, uint32_t n, uint32_t N)
+{
+    if (!shape_ok(n, N, 1)) return 0;
+    return elem_size == 8 ? cluster_members<double>(n, N) : cluster_members<float>(n, N);
 }
 
 size_t gbdpcg_pcg_shared_mem_size(uint32_t elem_size, uint32_t n, uint32_t N)

@@ -1,0 +1,91 @@
+// bt_dense.hpp -- the register-resident ("dense") lane map shared by pcg_resident.hip (one workgroup per problem) and
+// pcg_cluster.hip (a problem over a few workgroups): a lane owns V whole rows of one block-row of [L|D|R].
+#pragma once
+
+#include "bt_device.hpp"
+
+namespace gbdpcg {
+
+// When both matrices of a problem fit the register file of ONE 8-wave workgroup they are read from
+// HBM exactly once and an iteration touches only LDS.  This is the reference's own idea (its
+// block-rows sit in shared memory for the whole solve, pcg.cuh:104-110) moved one level up the
+// hierarchy, with the whole problem inside one workgroup so that no grid barrier exists.
+//
+// Lane map (different from the streaming one, where every instruction must be a dense global read):
+// a lane owns V whole ROWS of one block-row -- all 3n columns, 3n*V registers per matrix -- so a
+// block-row product is 3n FMAs per row with NO cross-lane fold, columns accumulated in ascending
+// order exactly like bdmv (utils.cuh:77-81).  n/V lanes make a block-row, BPW = 64/(n/V) block-rows
+// make a wave (n=14, V=2: 7 lanes x 9 block-rows = 63 lanes; the reference keeps n of 64 threads
+// busy), 8 waves cover N <= 8*BPW knots.  x is read from LDS as 8/16-byte pairs shared by the lanes
+// of a block-row.  Edge columns (L_0, R_{N-1}) and rows past N are zeroed once, at load time.
+template <typename T, int NCT, int V> struct DenseGeom {
+    static constexpr uint32_t N_ = NCT > 0 ? NCT : 2;
+    static constexpr uint32_t LPB = N_ / V > 0 ? N_ / V : 1;  // lanes per block-row
+    static constexpr uint32_t BPW = kWave / LPB;        // block-rows per wave
+    static constexpr uint32_t COLS = 3 * N_;
+    static constexpr uint32_t REGS = COLS * V * sizeof(T) / 4;  // VGPRs per lane per matrix
+    static constexpr uint32_t WAVES = 8;
+    static constexpr uint32_t MAX_KNOTS = WAVES * BPW;
+};
+
+template <typename T, int NCT, int V> struct DenseTile {
+    T a[DenseGeom<T, NCT, V>::COLS][V];
+};
+
+template <typename T, int NCT, int V> struct DenseCtx {
+    uint32_t k;       // this lane's block-row (knot index in the problem)
+    uint32_t kl;      // ... counted from the first knot of the workgroup (== k when the workgroup has the whole problem)
+    uint32_t rp;      // row group inside it
+    bool live;        // lane maps to a real row of a real block-row
+    // the workgroup holds knots [k_lo, k_lo + cnt)
+    __device__ __forceinline__ DenseCtx(uint32_t wave, uint32_t lane, uint32_t cnt, uint32_t k_lo = 0) {
+        using Dg = DenseGeom<T, NCT, V>;
+        const uint32_t b = lane / Dg::LPB;
+        rp = lane - b * Dg::LPB;
+        kl = wave * Dg::BPW + b;
+        k = k_lo + kl;
+        live = b < Dg::BPW && kl < cnt;
+    }
+};
+
+template <typename T, int NCT, int V>
+__device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, const DenseCtx<T, NCT, V> &dc,
+                                           DenseTile<T, NCT, V> &tl)
+{
+    using Dg = DenseGeom<T, NCT, V>;
+    const uint32_t k = dc.live ? dc.k : 0u;
+    const T *src = M + (size_t)k * 3 * Dg::N_ * Dg::N_ + dc.rp * V;
+    const uint32_t c_lo = dc.k == 0 ? Dg::N_ : 0u, c_hi = dc.k == N - 1 ? 2 * Dg::N_ : 3 * Dg::N_;
+#pragma unroll
+    for (uint32_t c = 0; c < Dg::COLS; ++c) {
+        T v[V];
+        VecIO<T, V>::load(src + c * Dg::N_, v);
+        const bool keep = dc.live && c >= c_lo && c < c_hi;
+#pragma unroll
+        for (int j = 0; j < V; ++j) tl.a[c][j] = keep ? v[j] : T(0);
+    }
+}
+
+// y_k = [L|D|R]_k * X-window for this lane's rows, left in registers.  X: the operand with one knot of padding in
+// front of the workgroup's first knot (zeros, or the neighbouring workgroup's boundary knot).
+template <typename T, int NCT, int V>
+__device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T *X, const DenseCtx<T, NCT, V> &dc,
+                                         T (&acc)[V])
+{
+    using Dg = DenseGeom<T, NCT, V>;
+    using P2 = typename VecOf<T, 2>::type;
+    const uint32_t kl = dc.live ? dc.kl : 0u;
+    const P2 *xk = reinterpret_cast<const P2 *>(X + kl * Dg::N_);  // column c of local row kl multiplies X[kl*n + c]
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = T(0);
+#pragma unroll
+    for (uint32_t c = 0; c < Dg::COLS; c += 2) {
+        const P2 xv = xk[c / 2];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fma_t(tl.a[c][j], xv.x, acc[j]);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fma_t(tl.a[c + 1][j], xv.y, acc[j]);
+    }
+}
+
+}  // namespace gbdpcg

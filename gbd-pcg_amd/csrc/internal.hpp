@@ -55,6 +55,9 @@ template <typename T> struct PcgArgs {
     // Split path, blocking entry points only: a counter in host-visible memory that a problem bumps when
     // it converges, so that the host can stop enqueueing iteration launches (nullptr: not used).
     uint32_t *host_done = nullptr;
+    // Cluster path (pcg_cluster.hip): the handle's hand-off slots (cluster_workspace_bytes, zero between launches);
+    // nullptr: the path is not offered.
+    void *cluster_ws = nullptr;
 };
 
 // Widest per-lane vector (in elements) usable for this block size and these base pointers:
@@ -92,6 +95,14 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
 template <typename T> bool resident_sym_shape(uint32_t n, uint32_t N);
 template <typename T>
 bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
+
+// ---- pcg_cluster.hip : general-storage matrices register-resident, a problem over a cluster of 2-4 workgroups (CUs)
+// Workgroups per problem the cluster path would use; 0 = shape not handled (n = 14, fp32, 72 < N <= 288 only).
+template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N);
+size_t cluster_workspace_bytes(const DeviceInfo &dev);
+// Returns false when the launch is not eligible (then nothing was launched).
+template <typename T>
+bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
 
 // ---- pcg_split.hip : many workgroups per problem, two launches per iteration
 template <typename T> size_t split_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);

@@ -1,0 +1,412 @@
+// pcg_cluster.hip -- PCG with both GENERAL-storage matrices register-resident, a problem spread over a CLUSTER of 2-4 CUs.
+//
+// Replaces pcg<T,n,N> (/root/reference/include/pcg.cuh:54-218) for the BASELINE batch shape (n = 14, fp32, N = 128) when
+// the storage is not bit-symmetric (pcg_resident_sym.hip does not apply) and for 72 < N <= 288 in general.  The reference
+// keeps all three blocks [L|D|R] of a knot of S and Pinv next to the ALUs for the whole solve (pcg.cuh:104-110); at this
+// shape that is 602 KB per problem, more than one CU holds (512 KB of registers + 160 KB of LDS), so the problem is cut
+// into H = ceil(N / 72) runs of consecutive knots and each run is given to one 8-wave workgroup with the lane map of
+// pcg_resident.hip (bt_dense.hpp: 2 x 84 VGPRs of matrix data per lane, no cross-lane fold).  The matrices are read from
+// HBM once per solve; an iteration touches LDS, registers and the hand-off words below.
+//
+// What crosses between the workgroups of a cluster, twice per iteration (the two inner products of PCG depend on each
+// other) and in ONE go each time: the 8 wave partials of the inner product and the boundary knot of the product vector
+// that the neighbour needs; the neighbour then updates its halo copy of r / p with the same fma the owner uses (same bits).
+// Every workgroup sums all 8H partials in the same order -> the exit test of pcg.cuh:195 is uniform over the cluster --
+// what pcg.cuh:147,167,191 ensure with their redundant per-block sums.  Hand-off words are data-tagged 8-byte granules
+// {value, epoch} written with sc1 (write-through) stores and polled with sc1 loads: the data is the flag, no fence
+// (MI355X_MICROARCH.md, Valid forms, R2; the same protocol as pcg_persist.hip).  One such hand-off between two CUs costs
+// 0.44-0.56 us (tools/hop_probe.hip), against 1.4-2 us for the chip-wide all-gather of the persistent path.
+//
+// Epochs start at 1 in every launch and slots hold 0 between launches: the workgroup that finishes LAST (an agent-scope
+// counter tells it) clears the slots once every other workgroup has drained its stores, so nothing has to be initialised
+// by a launch of its own and a solve stays ONE kernel node in a hipGraph.  A cluster's workgroups must be resident
+// together: the grid never exceeds one workgroup per CU, members of a cluster have neighbouring block indices (in-order
+// dispatch then splits at most one cluster at a time, and that one only until any workgroup exits), and every spin is
+// bounded: a cluster that cannot complete a hand-off reports max_iter_exit = 2, iters = 0xffffffff for its problems.
+#include <cstdlib>
+
+#include "bt_dense.hpp"
+#include "bt_device.hpp"
+#include "internal.hpp"
+
+namespace gbdpcg {
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int cl_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on gfx950: bit 4 = sc1
+
+// Workspace: [256-byte control block | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
+//   +0    the 8 wave partials (8 granules)
+//   +128  the first own knot of the product vector, for the left neighbour  (n granules, two per 16-byte store)
+//   +256  the last own knot, for the right neighbour
+constexpr uint32_t kClCtrlBytes = 256, kClSlotBytes = 384, kClFirstOff = 128, kClLastOff = 256;
+constexpr uint32_t kClMaxH = 4;
+
+__device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
+
+// Lane roles of the polling wave in one gather: lanes [0, 4H) fetch two wave partials each (member L / 4, waves
+// 2 (L % 4), +1), lanes [32, 39) the left neighbour's last knot, lanes [40, 47) the right neighbour's first knot.
+constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
+
+}  // namespace
+
+template <int NCT, int V>
+__global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsigned char *ws, uint32_t H, uint32_t C,
+                                                          uint32_t clusters, uint32_t spin_limit, uint32_t drop_block)
+{
+    using Dg = DenseGeom<float, NCT, V>;
+    static_assert(NCT == 14 && V == 2 && Dg::WAVES == 8, "lane roles below are written for 7 lanes x 2 rows per knot");
+    constexpr uint32_t n = NCT, THREADS = Dg::WAVES * 64, WINF = align16<float>((Dg::MAX_KNOTS + 2) * n);
+    __shared__ __attribute__((aligned(16))) float xa[WINF];   // window of p (lambda in the prologue): halo knot, own knots, halo knot
+    __shared__ __attribute__((aligned(16))) float xb[WINF];   // window of r
+    __shared__ float bc[4];       // [0] alpha / eta' of the phase just gathered, [1] beta
+    __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out
+
+    const uint32_t N = a.N, len = n * N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t grid = gridDim.x, blk = blockIdx.x;
+    // cluster c, member h.  Members sit 8 blocks apart where the cluster count allows it: blocks b and b + 8 share an XCD
+    // under round-robin dispatch (a hand-off inside one L2 is ~20 % shorter).  Speed only: nothing depends on placement.
+    const bool spread = clusters % 8 == 0;
+    const uint32_t c = spread ? (blk / (8 * H)) * 8 + blk % 8 : blk / H;
+    const uint32_t h = spread ? (blk % (8 * H)) / 8 : blk % H;
+    auto block_of = [&](uint32_t member) { return spread ? (c / 8) * 8 * H + member * 8 + c % 8 : c * H + member; };
+    const uint32_t k_lo = h * C, cnt = k_lo < N ? (N - k_lo < C ? N - k_lo : C) : 0u;   // host: cnt >= 1 for every member
+    const bool has_left = h > 0, has_right = h + 1 < H;
+
+    const DenseCtx<float, NCT, V> dc(wave, lane, cnt, k_lo);
+    const uint32_t row0 = (dc.live ? dc.kl : 0u) * n + dc.rp * V;    // first of this lane's rows, counted from knot k_lo
+    const size_t grow0 = (size_t)k_lo * n + row0;                     // ... in the problem's vectors
+    const bool first_knot = dc.live && dc.kl == 0, last_knot = dc.live && dc.kl + 1 == cnt;
+    const uint32_t wl = (cnt - 1) / Dg::BPW;                          // the wave that owns the last knot
+    const uint32_t POLL = wl == 7 ? 6u : 7u;                          // the polling wave: never wave 0, never wave wl
+    const size_t mstride = (size_t)3 * n * n * N;
+
+    unsigned char *slots = ws + kClCtrlBytes;
+    const __amdgpu_buffer_rsrc_t region =
+        __builtin_amdgcn_make_buffer_rsrc(slots, 0, (int)(2u * grid * kClSlotBytes), 0x00020000);
+    const uint32_t my_slot = blk * kClSlotBytes, par_stride = grid * kClSlotBytes;
+    // what this lane of the polling wave fetches in a gather (byte offset inside a parity's slots), if anything
+    uint32_t poll_off = 0;
+    bool poll_need = false;
+    if (lane < 4 * H) {
+        poll_off = block_of(lane / 4) * kClSlotBytes + (lane % 4) * 16;
+        poll_need = true;
+    } else if (lane >= kClLeftLane && lane < kClLeftLane + n / 2 && has_left) {
+        poll_off = block_of(h - 1) * kClSlotBytes + kClLastOff + (lane - kClLeftLane) * 16;
+        poll_need = true;
+    } else if (lane >= kClRightLane && lane < kClRightLane + n / 2 && has_right) {
+        poll_off = block_of(h + 1) * kClSlotBytes + kClFirstOff + (lane - kClRightLane) * 16;
+        poll_need = true;
+    }
+    // the halo entries of a window this lane of the polling wave rewrites after a gather
+    const bool halo_lane = poll_need && lane >= kClLeftLane;
+    const uint32_t halo_idx = lane >= kClRightLane ? (cnt + 1) * n + (lane - kClRightLane) * 2 : (lane - kClLeftLane) * 2;
+
+    // LDS is workgroup-private and the hand-off stores must not be waited for: a barrier that drains only the LDS counter
+#ifdef GBDPCG_CL_SYNCTHREADS   // diagnostic variant: the full barrier (also waits for the hand-off stores)
+    auto wg_barrier = [] { __syncthreads(); };
+#else
+    auto wg_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#endif
+
+    // One hand-off.  Every wave publishes its share PART of the inner product; the lanes that own the first / last knot
+    // publish the two values V0, V1 of their rows.  The polling wave then gathers the 8H partials and the neighbours'
+    // boundary knots: TOTAL (wave-uniform, the same bits in every member) and, in its halo lanes, G0 / G1.
+#define GBDPCG_CL_HANDOFF(EPOCH, PART, V0, V1, TOTAL, G0, G1, OK)                                                   \
+    {                                                                                                                \
+        const uint32_t tag = (EPOCH), par_off = (tag & 1u) * par_stride;                                             \
+        if (blk != drop_block) {                                                                                     \
+            if (lane == 0) {                                                                                         \
+                const cl_u32x2 x = {fbits(PART), tag};                                                               \
+                __builtin_amdgcn_raw_buffer_store_b64(x, region, (int)(par_off + my_slot + wave * 8), 0, kClSc1);    \
+            }                                                                                                        \
+            const cl_u32x4 bx = {fbits(V0), tag, fbits(V1), tag};                                                    \
+            if (first_knot && has_left)                                                                              \
+                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClFirstOff + dc.rp * 16), 0, kClSc1); \
+            if (last_knot && has_right)                                                                              \
+                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClLastOff + dc.rp * 16), 0, kClSc1);  \
+        }                                                                                                            \
+        if (wave == POLL) {                                                                                          \
+            bool have = !poll_need;                                                                                  \
+            cl_u32x4 got = {0u, 0u, 0u, 0u};                                                                         \
+            OK = true;                                                                                               \
+            for (uint32_t spins = 0;; ++spins) {                                                                     \
+                asm volatile("" ::: "memory");   /* the poll is re-issued on every pass */                           \
+                if (!have) {   /* only the lanes that still miss their piece load again */                           \
+                    got = __builtin_amdgcn_raw_buffer_load_b128(region, (int)(par_off + poll_off), 0, kClSc1);       \
+                    have = got.y == tag && got.w == tag;                                                             \
+                }                                                                                                    \
+                if (__all(have)) break;                                                                              \
+                if (spins >= spin_limit) {                                                                           \
+                    OK = false;                                                                                      \
+                    break;                                                                                           \
+                }                                                                                                    \
+                __builtin_amdgcn_s_sleep(1);                                                                         \
+            }                                                                                                        \
+            /* by value: __builtin_bit_cast applied to the element expression got.z itself reads element 0 (hipcc,   \
+               ROCm 7.2) */                                                                                          \
+            const uint32_t gx = got.x, gz = got.z;                                                                   \
+            G0 = __builtin_bit_cast(float, gx);                                                                      \
+            G1 = __builtin_bit_cast(float, gz);                                                                      \
+            TOTAL = wave_sum(lane < 4 * H ? G0 + G1 : 0.f);                                                          \
+        }                                                                                                            \
+    }
+
+    uint32_t published = 0;   // did this workgroup write any slot?  (the last finisher clears them only if someone did)
+    bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are reported, not solved
+    uint32_t ordinal = 0;     // problems of this cluster so far: the epochs of a problem continue where the last one stopped
+    const uint32_t epochs_per_problem = 2u * a.max_iter + 4u;
+
+    for (uint32_t prob = c; prob < a.batch; prob += clusters, ++ordinal) {
+        if (!pcg_takes(a, prob)) continue;   // this launch is not the one that owns the problem (same verdict in every member)
+        if (dead) {
+            if (h == 0 && tid == 0) {
+                a.iters[prob] = 0xffffffffu;
+                if (a.max_iter_exit) a.max_iter_exit[prob] = 2;
+            }
+            continue;
+        }
+        published = 1;
+        const uint32_t e0 = ordinal * epochs_per_problem;   // epochs e0 + 1 .. e0 + 2 max_iter + 2 belong to this problem
+        const float *S = a.S + prob * mstride;
+        const float *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;   // nullptr: identity preconditioner
+        const size_t voff = (size_t)prob * len;
+
+        DenseTile<float, NCT, V> tS, tP;
+        dense_load<float, NCT, V>(S, N, dc, tS);
+        if (P) dense_load<float, NCT, V>(P, N, dc, tP);
+
+        float lamv[V], rv[V], pv[V], yv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) lamv[j] = dc.live ? a.lambda[voff + grow0 + j] : 0.f;
+        // windows: zero everywhere (rows past the own knots, halos at the ends of the problem), then lambda with its halos
+        // straight from the input vector (no member writes lambda before every member has passed its first hand-off)
+        for (uint32_t i = tid; i < WINF; i += THREADS) {
+            const int64_t gi = (int64_t)k_lo * n - n + i;
+            xa[i] = (i < (cnt + 2) * n && gi >= 0 && gi < (int64_t)len) ? a.lambda[voff + gi] : 0.f;
+            xb[i] = 0.f;
+        }
+        if (tid == 0) bci[0] = 0u;
+        wg_barrier();
+
+        float total = 0.f, g0 = 0.f, g1 = 0.f, part;
+        bool ok = true;
+        // r = gamma - S lambda                                            (pcg.cuh:118-126); the boundary knots of r travel
+        dense_mv<float, NCT, V>(tS, xa, dc, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) rv[j] = dc.live ? a.gamma[voff + grow0 + j] - yv[j] : 0.f;
+        if (dc.live) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) xb[n + row0 + j] = rv[j];
+        }
+        GBDPCG_CL_HANDOFF(e0 + 1u, 0.f, rv[0], rv[1], total, g0, g1, ok)
+        if (wave == POLL) {
+            if (!ok && lane == 0) bci[0] = 2u;
+            if (ok && halo_lane) { xb[halo_idx] = g0; xb[halo_idx + 1] = g1; }
+        }
+        wg_barrier();
+        bool failed = bci[0] == 2u;
+
+        // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
+        float eta = 0.f;
+        if (!failed) {
+            if (P) dense_mv<float, NCT, V>(tP, xb, dc, yv);
+            part = 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                pv[j] = P ? yv[j] : rv[j];
+                part = fma_t(rv[j], pv[j], part);
+            }
+            part = wave_sum(part);
+            if (dc.live) {   // every read of xa (as lambda) happened before the last barrier
+#pragma unroll
+                for (int j = 0; j < V; ++j) xa[n + row0 + j] = pv[j];
+            }
+            GBDPCG_CL_HANDOFF(e0 + 2u, part, pv[0], pv[1], total, g0, g1, ok)
+            if (wave == POLL) {
+                if (lane == 0) {
+                    if (!ok) bci[0] = 2u;
+                    bc[0] = total;
+                }
+                if (ok && halo_lane) { xa[halo_idx] = g0; xa[halo_idx + 1] = g1; }
+            }
+            wg_barrier();
+            failed = bci[0] == 2u;
+            eta = bc[0];
+        }
+
+        uint32_t iter = 0;
+        bool max_iter_exit = true;
+        for (; !failed && iter < a.max_iter; ++iter) {                    // pcg.cuh:154
+            // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
+            dense_mv<float, NCT, V>(tS, xa, dc, yv);
+            part = 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) part = fma_t(pv[j], yv[j], part);
+            part = wave_sum(part);
+            GBDPCG_CL_HANDOFF(e0 + 3u + 2u * iter, part, yv[0], yv[1], total, g0, g1, ok)
+            if (wave == POLL) {
+                const float al = eta / total;
+                if (lane == 0) {
+                    if (!ok) bci[0] = 2u;
+                    bc[0] = al;
+                }
+                // r -= alpha upsilon on the halo knots: the owner's fma on the owner's bits
+                if (ok && halo_lane) {
+                    xb[halo_idx] = fma_t(-al, g0, xb[halo_idx]);
+                    xb[halo_idx + 1] = fma_t(-al, g1, xb[halo_idx + 1]);
+                }
+            }
+            wg_barrier();
+            if (bci[0] == 2u) { failed = true; break; }
+            const float alpha = bc[0];
+            // lambda += alpha p ; r -= alpha upsilon                      (pcg.cuh:172-176)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                lamv[j] = fma_t(alpha, pv[j], lamv[j]);
+                rv[j] = fma_t(-alpha, yv[j], rv[j]);
+            }
+            if (dc.live) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) xb[n + row0 + j] = rv[j];
+            }
+            wg_barrier();
+            // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
+            if (P) dense_mv<float, NCT, V>(tP, xb, dc, yv);
+            part = 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (!P) yv[j] = rv[j];
+                part = fma_t(rv[j], yv[j], part);
+            }
+            part = wave_sum(part);
+            GBDPCG_CL_HANDOFF(e0 + 4u + 2u * iter, part, yv[0], yv[1], total, g0, g1, ok)
+            if (wave == POLL) {
+                const bool conv = fabsf(total) < a.tol;                   // pcg.cuh:195
+                const float be = total / eta;                             // pcg.cuh:199
+                if (lane == 0) {
+                    bci[0] = !ok ? 2u : (conv ? 1u : 0u);
+                    bc[0] = total;
+                    bc[1] = be;
+                }
+                // p = r~ + beta p on the halo knots                       (pcg.cuh:203-206)
+                if (ok && !conv && halo_lane) {
+                    xa[halo_idx] = fma_t(be, xa[halo_idx], g0);
+                    xa[halo_idx + 1] = fma_t(be, xa[halo_idx + 1], g1);
+                }
+            }
+            wg_barrier();
+            const uint32_t verdict = bci[0];
+            if (verdict == 2u) { failed = true; break; }
+            if (verdict == 1u) {
+                ++iter;
+                max_iter_exit = false;
+                break;
+            }
+            const float beta = bc[1];
+            eta = bc[0];
+#pragma unroll
+            for (int j = 0; j < V; ++j) pv[j] = fma_t(beta, pv[j], yv[j]);
+            if (dc.live) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) xa[n + row0 + j] = pv[j];
+            }
+            wg_barrier();
+        }
+
+        // outputs                                                         (pcg.cuh:212,215)
+        if (dc.live && !failed) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                a.lambda[voff + grow0 + j] = lamv[j];
+                if (a.r) a.r[voff + grow0 + j] = rv[j];
+                if (a.p) a.p[voff + grow0 + j] = pv[j];
+            }
+        }
+        if (h == 0 && tid == 0) {
+            a.iters[prob] = failed ? 0xffffffffu : iter;
+            if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (max_iter_exit ? 1 : 0);
+        }
+        dead = failed;
+        wg_barrier();   // the windows and bci are reused by the next problem
+    }
+#undef GBDPCG_CL_HANDOFF
+
+    // ---- leave the slots zeroed for the next launch --------------------------------------------------------------
+    // Every wave drains its stores, the workgroup meets, one thread counts it in; the workgroup whose add comes last
+    // knows that every other one has drained (no store of this launch can land after the clearing) and, if anyone
+    // published, zeroes all slots and the counter.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ uint32_t last_one;
+    __syncthreads();
+    if (tid == 0) {
+        u64 *ctr = reinterpret_cast<u64 *>(ws);
+        const u64 before = __hip_atomic_fetch_add(ctr, 1ull + ((u64)published << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = (uint32_t)before == grid - 1u;
+        last_one = last ? (((before >> 32) + published) != 0 ? 2u : 1u) : 0u;
+    }
+    __syncthreads();
+    if (last_one != 0u) {
+        if (last_one == 2u) {
+            const cl_u32x4 z = {0u, 0u, 0u, 0u};
+            for (uint32_t off = tid * 16; off < 2u * grid * kClSlotBytes; off += THREADS * 16)
+                __builtin_amdgcn_raw_buffer_store_b128(z, region, (int)off, 0, kClSc1);
+        }
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(ws), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// n = 14, fp32, general storage, 72 < N <= 288.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
+template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
+{
+    static const bool off = getenv("GBDPCG_NO_CLUSTER") != nullptr;
+    if (off || sizeof(T) != 4 || n != 14) return 0;
+    constexpr uint32_t per_wg = DenseGeom<float, 14, 2>::MAX_KNOTS;
+    if (N <= per_wg) return 0;   // pcg_resident.hip has it in one workgroup
+    const uint32_t H = (N + per_wg - 1) / per_wg;
+    return H <= kClMaxH ? H : 0;
+}
+
+size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (size_t)2 * dev.num_cus * kClSlotBytes; }
+
+template <typename T>
+bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
+{
+    if constexpr (sizeof(T) == 4) {
+        const uint32_t H = cluster_members<T>(a.n, a.N);
+        if (H == 0 || !a.cluster_ws || a.symmetric) return false;
+        if ((reinterpret_cast<uintptr_t>(a.S) % 8) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 8)) return false;
+        uint32_t clusters = (uint32_t)dev.num_cus / H;   // one workgroup per CU: a cluster's members are resident together
+        if (clusters > a.batch) clusters = a.batch;
+        if (clusters == 0) return false;
+        const uint32_t rounds = (a.batch + clusters - 1) / clusters;
+        if ((double)rounds * (2.0 * a.max_iter + 4.0) > 4.0e9) return false;   // epochs are 32-bit tags
+        const uint32_t C = (a.N + H - 1) / H;
+        static const uint32_t spin_limit = [] {   // polls before a hand-off is given up (test hook; ~1 us per poll)
+            const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT");
+            return e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 21);
+        }();
+        static const uint32_t drop_block = [] {   // test hook: a workgroup that never publishes
+            const char *e = getenv("GBDPCG_CLUSTER_DROP_WG");
+            return e ? (uint32_t)strtoul(e, nullptr, 10) : 0xffffffffu;
+        }();
+        hipLaunchKernelGGL((pcg_cluster_kernel<14, 2>), dim3(clusters * H), dim3(512), 0, s, a,
+                           static_cast<unsigned char *>(a.cluster_ws), H, C, clusters, spin_limit, drop_block);
+        *err = hipGetLastError();
+        return true;
+    } else {
+        return false;
+    }
+}
+
+template uint32_t cluster_members<float>(uint32_t, uint32_t);
+template uint32_t cluster_members<double>(uint32_t, uint32_t);
+template bool launch_pcg_cluster<float>(const DeviceInfo &, const PcgArgs<float> &, hipStream_t, hipError_t *);
+template bool launch_pcg_cluster<double>(const DeviceInfo &, const PcgArgs<double> &, hipStream_t, hipError_t *);
+
+}  // namespace gbdpcg

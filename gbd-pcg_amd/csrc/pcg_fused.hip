@@ -335,6 +335,7 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
     hipError_t rerr = hipSuccess;
     if (launch_pcg_resident<T>(dev, a, s, &rerr)) return rerr;  // small problems: pcg_resident.hip
     if (a.symmetric && launch_pcg_resident_sym<T>(dev, a, s, &rerr)) return rerr;  // pcg_resident_sym.hip
+    if (!a.symmetric && launch_pcg_cluster<T>(dev, a, s, &rerr)) return rerr;      // general storage over 2-4 CUs: pcg_cluster.hip
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
     if (V == 0) return hipErrorInvalidValue;

@@ -64,8 +64,8 @@ typedef enum gbdpcg_path {
                                   d_iters = 0xffffffff (result invalid; use GBDPCG_PATH_SPLIT for such callers). */
     GBDPCG_PATH_PERSISTENT_1R = 4 /* OPT-IN, never chosen by AUTO: the persistent launch with the single-reduction
                                   (Chronopoulos-Gear) recurrence -- u = Pinv r, w = S u, gamma = r.u and delta = u.w in ONE
-                                  all-gather per iteration, alpha = gamma / (delta - beta gamma / alpha_old), s = S p by
-                                  recurrence.  Same iterates and the same exit test as pcg.cuh:154-206 in exact arithmetic,
+                                  all-gather per iteration (the halo knots of u are recomputed, not exchanged),
+                                  alpha = gamma / (delta - beta gamma / alpha_old), s = S p by recurrence.  Same iterates and the same exit test as pcg.cuh:154-206 in exact arithmetic,
                                   a different rounding sequence: equal iteration counts and fp64 lambda within 1e-13 of the
                                   default path on the test shapes, but not the reference's recurrence. */
 } gbdpcg_path;
@@ -100,6 +100,11 @@ gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path);
 /* Path AUTO would take for this shape (elem_size 4 or 8). */
 gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
                                uint32_t batch);
+/* Compute units a GENERAL-storage problem of this shape is spread over inside the fused path (pcg_cluster.hip: both
+ * matrices register-resident for the whole solve, 2-4 workgroups per problem exchanging inner-product partials and
+ * boundary knots twice per iteration); 0 = the shape has no such form (stateSize 14, fp32, 72 < knotPoints <= 288 only)
+ * and general storage is streamed every iteration. */
+uint32_t gbdpcg_cluster_members(uint32_t elem_size, uint32_t n, uint32_t N);
 
 /* Symmetric storage.  S and Pinv of an MPC Schur system are symmetric block-tridiagonal, i.e. in
  * storage L_{k+1} == R_k^T for every knot (README.md:8; the symmetric-stair preconditioner of

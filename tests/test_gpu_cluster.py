@@ -1,0 +1,212 @@
+"""The cluster path (csrc/pcg_cluster.hip): general-storage problems of stateSize 14, fp32, 72 < knotPoints <= 288 with both
+matrices register-resident over 2-4 compute units, against the CPU oracle, through the C ABI.  It is what the fused path
+runs when the symmetric kernels do not apply (symmetric mode 0, or storage that fails the bit-for-bit test).  Tolerances as
+in test_gpu_parity.py: fp32 1e-6 norm-wise, equal iteration counts on the a = 0.5 generator."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from gbd_pcg_amd import binding, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def solver():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    s = binding.Solver(0)
+    yield s
+    s.close()
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def unsymmetrize(M, n, N, B, every=1):
+    """Make the storage of every `every`-th problem fail the bit-for-bit symmetry test without changing the matrix much:
+    one element of one L block is moved by one ulp."""
+    M = M.reshape(B, N, 3, n, n).copy()
+    for b in range(0, B, every):
+        k = 1 + (7 * b) % (N - 1)
+        M[b, k, 0, 3, 5] = np.nextafter(M[b, k, 0, 3, 5], np.float32(np.inf))
+    return M.reshape(B, -1)
+
+
+def run(solver, n, N, B, S, Pinv, gamma, lam0=None, tol=1e-6, max_iter=100, symmetric=0):
+    assert solver.cluster_members(4, n, N) >= 2, "shape has no cluster form"
+    assert solver.choose_path(4, n, N, B) == binding.PATH_FUSED
+    solver.set_symmetric(symmetric)
+    try:
+        dS, dP, dg = dev(S), dev(Pinv), dev(gamma)
+        lam = torch.zeros_like(dg) if lam0 is None else dev(lam0)
+        r, p = torch.full_like(dg, float("nan")), torch.full_like(dg, float("nan"))
+        it, fl = solver.solve(n, N, B, dS, dP, dg, lam, r, p, tol=tol, max_iter=max_iter)
+        torch.cuda.synchronize()
+    finally:
+        solver.set_symmetric(2)
+    return dict(lambda_=lam.cpu().numpy().reshape(B, -1), r=r.cpu().numpy().reshape(B, -1),
+                p=p.cpu().numpy().reshape(B, -1), iters=it.cpu().numpy().astype(np.int64),
+                flag=fl.cpu().numpy().astype(np.int64))
+
+
+def check(out, ob, d, B, ltol=1e-6, vtol=2e-5):
+    assert np.array_equal(out["iters"], ob["iters"].astype(np.int64)), (out["iters"], ob["iters"])
+    assert np.array_equal(out["flag"], ob["max_iter_exit"].astype(np.int64))
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < ltol, b
+        scale = np.abs(d["gamma"][b]).max()
+        assert np.abs(out["r"][b] - ob["r"].reshape(B, -1)[b]).max() < vtol * scale, b
+        assert np.abs(out["p"][b] - ob["p"].reshape(B, -1)[b]).max() < vtol * scale, b
+
+
+def test_cluster_shapes(solver):
+    assert solver.cluster_members(4, 14, 128) == 2 and solver.cluster_members(4, 14, 144) == 2
+    assert solver.cluster_members(4, 14, 145) == 3 and solver.cluster_members(4, 14, 288) == 4
+    assert solver.cluster_members(4, 14, 72) == 0      # one workgroup holds it (pcg_resident.hip)
+    assert solver.cluster_members(4, 14, 289) == 0 and solver.cluster_members(8, 14, 128) == 0
+    assert solver.cluster_members(4, 36, 128) == 0
+
+
+@pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (73, 2), (100, 9), (144, 3), (145, 2), (200, 4), (216, 1), (217, 2), (288, 3)])
+def test_cluster_vs_oracle(solver, orc, N, B):
+    """Two, three and four workgroups per problem, even and ragged splits, more and fewer problems than one round."""
+    n = 14
+    d = synth.gen_numpy(n, N, seed=500 + N, batch=B, dtype=np.float32)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"])
+    check(out, ob, d, B)
+
+
+def test_cluster_identity_preconditioner(solver, orc):
+    """d_Pinv == NULL: r~ = r (pcg.cuh with an identity preconditioner); more iterations, same rules."""
+    n, N, B = 14, 128, 4
+    d = synth.gen_numpy(n, N, seed=21, batch=B, dtype=np.float32)
+    ob = orc.pcg_batch(n, N, B, d["S"], None, d["gamma"], tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, d["S"], None, d["gamma"])
+    assert np.abs(out["iters"] - ob["iters"].astype(np.int64)).max() <= 3   # unpreconditioned: order-sensitive (test_gpu_parity.py)
+    assert not out["flag"].any()
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < 2e-5
+
+
+def test_cluster_takes_what_the_symmetry_test_rejects(solver, orc):
+    """Default (tested) symmetric mode: storage that is symmetric goes to the CU-resident symmetric kernel, storage that
+    is off by one ulp in one element goes to the cluster kernel -- in one call, each problem equal to the oracle run on the
+    very matrices it was given."""
+    n, N, B = 14, 128, 24
+    d = synth.gen_numpy(n, N, seed=611, batch=B, dtype=np.float32)
+    S = unsymmetrize(d["S"], n, N, B, every=3)
+    Pinv = unsymmetrize(d["Pinv"], n, N, B, every=4)
+    ob = orc.pcg_batch(n, N, B, S, Pinv, d["gamma"], tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, S, Pinv, d["gamma"], symmetric=2)
+    check(out, ob, d, B)
+
+
+@pytest.mark.parametrize("tol,max_iter", [(1e-6, 0), (1e-6, 1), (1e30, 5), (0.0, 2), (0.0, 7)])
+def test_cluster_iteration_edges(solver, orc, tol, max_iter):
+    n, N, B = 14, 128, 3
+    d = synth.gen_numpy(n, N, seed=78, batch=B, dtype=np.float32)
+    lam0 = (np.stack([synth.normals(5 + b, 0, n * N) for b in range(B)]) * 0.1).astype(np.float32)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], lambda0=lam0, tol=tol, max_iter=max_iter)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], lam0=lam0, tol=tol, max_iter=max_iter)
+    assert np.array_equal(out["iters"], ob["iters"].astype(np.int64))
+    assert np.array_equal(out["flag"], ob["max_iter_exit"].astype(np.int64))
+    scale = np.abs(d["gamma"]).max()
+    for key in ("lambda_", "r", "p"):
+        assert np.abs(out[key] - ob[key].reshape(B, -1)).max() < 2e-5 * max(scale, np.abs(ob[key]).max()), key
+
+
+def test_cluster_full_config3_batch(solver, orc):
+    """BASELINE config 3's batch (1024 problems, n = 14, N = 128) in general storage: eight rounds of 128 clusters.
+    Iteration counts in the band of the generator, true residuals small, and 64 problems spread over the rounds equal to
+    the oracle."""
+    n, N, B = 14, 128, 1024
+    d = synth.gen_numpy(n, N, seed=1234, batch=B, dtype=np.float32)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], max_iter=25)
+    assert out["iters"].min() >= 7 and out["iters"].max() <= 12 and not out["flag"].any()
+    idx = np.arange(0, B, 16)
+    ob = orc.pcg_batch(n, N, len(idx), d["S"][idx], d["Pinv"][idx], d["gamma"][idx], tol=1e-6, max_iter=25)
+    assert np.array_equal(out["iters"][idx], ob["iters"].astype(np.int64))
+    for j, b in enumerate(idx):
+        assert relerr(out["lambda_"][b], ob["lambda_"][j]) < 1e-6
+    for b in range(0, B, 37):   # true residual, fp64 product of the oracle
+        res = d["gamma"][b].astype(np.float64) - orc.spmv(n, N, d["S"][b].astype(np.float64), out["lambda_"][b].astype(np.float64))
+        assert np.linalg.norm(res) < 2e-3 * np.linalg.norm(d["gamma"][b])
+
+
+def test_cluster_replays_leave_clean_slots(solver, orc):
+    """Every launch starts its epochs at 1 and relies on the previous launch having zeroed the hand-off slots: a graph
+    replayed back to back, other shapes and iteration limits in between -- always the same answer."""
+    n, N, B = 14, 128, 200
+    d = synth.gen_numpy(n, N, seed=99, batch=B, dtype=np.float32)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=25)
+    first = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], max_iter=25)
+    assert np.array_equal(first["iters"], ob["iters"].astype(np.int64))
+    d2 = synth.gen_numpy(n, 200, seed=98, batch=3, dtype=np.float32)
+    run(solver, n, 200, 3, d2["S"], d2["Pinv"], d2["gamma"], tol=0.0, max_iter=3)   # three members, fixed iterations
+    solver.set_symmetric(0)
+    try:
+        dS, dP, dg = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+        lam = torch.zeros_like(dg)
+        r, p = torch.empty_like(dg), torch.empty_like(dg)
+        it = torch.zeros(B, dtype=torch.int32, device="cuda")
+        fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        gr = solver.graph_solve(n, N, B, dS, dP, dg, lam, r, p, 1e-6, 25, it, fl)
+        for _ in range(30):
+            lam.zero_()
+            gr.launch()
+        torch.cuda.synchronize()
+        gr.close()
+    finally:
+        solver.set_symmetric(2)
+    assert np.array_equal(it.cpu().numpy().astype(np.int64), first["iters"])
+    assert np.array_equal(lam.cpu().numpy().reshape(B, -1), first["lambda_"])   # same kernel, same inputs: same bits
+    again = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], max_iter=25)
+    assert np.array_equal(again["lambda_"], first["lambda_"])
+
+
+GIVE_UP = r"""
+import numpy as np, torch
+from gbd_pcg_amd import binding, synth
+n, N, B = 14, 128, 300
+d = synth.gen_numpy(n, N, seed=5, batch=B, dtype=np.float32)
+s = binding.Solver(0)
+s.set_symmetric(0)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+dS, dP, dg = t(d["S"]), t(d["Pinv"]), t(d["gamma"])
+lam = torch.zeros_like(dg)
+it, fl = s.solve(n, N, B, dS, dP, dg, lam, None, None, tol=1e-6, max_iter=25)
+torch.cuda.synchronize()
+it = it.cpu().numpy().astype(np.int64) & 0xffffffff; fl = fl.cpu().numpy()
+clusters = 128
+lost = np.arange(B) % clusters == 1          # block 1 is member 0 of cluster 1 (members sit 8 blocks apart)
+assert (it[lost] == 0xffffffff).all() and (fl[lost] == 2).all(), (it[lost], fl[lost])
+assert (it[~lost] < 20).all() and (fl[~lost] == 0).all()
+# the next launch (no dropped workgroup is a property of the process: same hook) still finds clean slots for the others
+lam.zero_()
+it2, fl2 = s.solve(n, N, B, dS, dP, dg, lam, None, None, tol=1e-6, max_iter=25)
+torch.cuda.synchronize()
+assert np.array_equal((it2.cpu().numpy().astype(np.int64) & 0xffffffff)[~lost], it[~lost])
+print("GIVE-UP-OK")
+"""
+
+
+def test_cluster_gives_up_instead_of_hanging():
+    """A workgroup that never publishes (test hook): its cluster reports max_iter_exit = 2 / iters = 0xffffffff for all of
+    its problems after a bounded spin, every other cluster is unaffected, and the slots are clean for the next launch."""
+    env = dict(os.environ, GBDPCG_CLUSTER_DROP_WG="1", GBDPCG_CLUSTER_SPIN_LIMIT="20000", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", GIVE_UP], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "GIVE-UP-OK" in out.stdout, out.stdout + out.stderr
