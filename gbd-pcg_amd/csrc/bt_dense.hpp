@@ -68,23 +68,49 @@ __device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, 
 
 // y_k = [L|D|R]_k * X-window for this lane's rows, left in registers.  X: the operand with one knot of padding in
 // front of the workgroup's first knot (zeros, or the neighbouring workgroup's boundary knot).
-template <typename T, int NCT, int V>
+// CHAINS = 1: one accumulator per row, columns in ascending order exactly like bdmv (utils.cuh:77-81).  CHAINS = 3: one
+// accumulator per block, y = (L x_{k-1} + D x_k) + R x_{k+1}, each block's columns ascending: three independent chains of
+// 14 packed fma's instead of one of 42 (a dependent v_pk_fma_f32 issues every ~10 cycles: the single chain cost
+// ~1,000 cycles per product with two waves per SIMD, measured in pcg_cluster.hip).
+template <typename T, int NCT, int V, int CHAINS = 1>
 __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T *X, const DenseCtx<T, NCT, V> &dc,
                                          T (&acc)[V])
 {
     using Dg = DenseGeom<T, NCT, V>;
     using P2 = typename VecOf<T, 2>::type;
+    static_assert(CHAINS == 1 || (CHAINS == 3 && Dg::N_ % 2 == 0), "one chain, or one per block (whole x pairs per block)");
     const uint32_t kl = dc.live ? dc.kl : 0u;
     const P2 *xk = reinterpret_cast<const P2 *>(X + kl * Dg::N_);  // column c of local row kl multiplies X[kl*n + c]
+    T part[CHAINS][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = T(0);
+    for (int q = 0; q < CHAINS; ++q)
 #pragma unroll
-    for (uint32_t c = 0; c < Dg::COLS; c += 2) {
-        const P2 xv = xk[c / 2];
+        for (int j = 0; j < V; ++j) part[q][j] = T(0);
+    if constexpr (CHAINS == 1) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fma_t(tl.a[c][j], xv.x, acc[j]);
+        for (uint32_t c = 0; c < Dg::COLS; c += 2) {
+            const P2 xv = xk[c / 2];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fma_t(tl.a[c + 1][j], xv.y, acc[j]);
+            for (int j = 0; j < V; ++j) part[0][j] = fma_t(tl.a[c][j], xv.x, part[0][j]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) part[0][j] = fma_t(tl.a[c + 1][j], xv.y, part[0][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = part[0][j];
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < Dg::N_; c += 2) {   // the three blocks side by side: independent work in every step
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const P2 xv = xk[(q * Dg::N_ + c) / 2];
+#pragma unroll
+                for (int j = 0; j < V; ++j) part[q][j] = fma_t(tl.a[q * Dg::N_ + c][j], xv.x, part[q][j]);
+#pragma unroll
+                for (int j = 0; j < V; ++j) part[q][j] = fma_t(tl.a[q * Dg::N_ + c + 1][j], xv.y, part[q][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = (part[0][j] + part[1][j]) + part[2][j];
     }
 }
 

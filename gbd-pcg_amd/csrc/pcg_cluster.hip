@@ -51,9 +51,67 @@ __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(u
 // 2 (L % 4), +1), lanes [32, 39) the left neighbour's last knot, lanes [40, 47) the right neighbour's first knot.
 constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
 
+#ifndef GBDPCG_CL_CHAINS
+#define GBDPCG_CL_CHAINS 3   // accumulator chains of a block-row product (bt_dense.hpp, dense_mv); 1 for A/B builds
+#endif
+
+// Staged tile loads.  A wave's knots are contiguous in memory; one block (L, D or R: n^2 floats = 49 pieces of 16 bytes)
+// of each of its up to 9 knots is fetched per stage with 7 LDS-DMA instructions (64 lanes x 16 bytes, dense and
+// coalesced, no VGPR in between) into the wave's own staging buffer, and the lanes then pick their two rows up with
+// 8-byte LDS reads.  The direct form (bt_dense.hpp, dense_load) reads 8 bytes per lane at a 56-byte stride: 84 sparse
+// instructions per matrix, bound by the address path -- 28 us of a 40 us round went there.
+constexpr uint32_t kClStageChunks = 7 * 64, kClStageBytes = kClStageChunks * 16, kClStageFloats = kClStageBytes / 4;
+constexpr uint32_t kClPieces = 49;   // 16-byte pieces per n x n block, n = 14
+
+// Issue one stage: lane l of instruction i moves 16 bytes from base + rel[i] to lds_addr + i * 1024 + l * 16.  The loads
+// are written in asm (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with
+// cluster_stage_wait before it reads the buffer, and never has more than two stages in flight.
+__device__ __forceinline__ void cluster_stage_issue(const float *base, const uint32_t (&rel)[7], uint32_t lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "s"(lds_addr)
+                 : "memory", "scc");
+}
+// all but the youngest `newer` stages (7 loads each) of this wave have landed
+template <int NEWER> __device__ __forceinline__ void cluster_stage_wait()
+{
+    if constexpr (NEWER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+}
+
+typedef float2 __attribute__((may_alias)) cl_float2_alias;
+
+// This lane's two rows of block BLK (0 = L, 1 = D, 2 = R) out of the wave's staging buffer into its tile.
+template <int NCT, int V, int BLK>
+__device__ __forceinline__ void cluster_stage_pick(const float *buf, const DenseCtx<float, NCT, V> &dc, uint32_t b9, uint32_t N,
+                                                   DenseTile<float, NCT, V> &tl)
+{
+    constexpr uint32_t n = NCT;
+    // L_0 and R_{N-1} are never used (pcg.cuh:105-106); lanes without a row hold zeros
+    const bool keep = dc.live && !(BLK == 0 && dc.k == 0) && !(BLK == 2 && dc.k == N - 1);
+    const cl_float2_alias *src = reinterpret_cast<const cl_float2_alias *>(buf + b9 * n * n + dc.rp * 2);
+#pragma unroll
+    for (uint32_t c = 0; c < n; ++c) {
+        const float2 v = src[c * n / 2];
+        tl.a[BLK * n + c][0] = keep ? v.x : 0.f;
+        tl.a[BLK * n + c][1] = keep ? v.y : 0.f;
+    }
+}
+
 }  // namespace
 
-template <int NCT, int V>
+template <int NCT, int V, bool STAGED>
 __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsigned char *ws, uint32_t H, uint32_t C,
                                                           uint32_t clusters, uint32_t spin_limit, uint32_t drop_block)
 {
@@ -64,6 +122,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     __shared__ __attribute__((aligned(16))) float xb[WINF];   // window of r
     __shared__ float bc[4];       // [0] alpha / eta' of the phase just gathered, [1] beta
     __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: [2][8 waves][kClStageBytes]
 
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -74,15 +133,22 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     const bool spread = clusters % 8 == 0;
     const uint32_t c = spread ? (blk / (8 * H)) * 8 + blk % 8 : blk / H;
     const uint32_t h = spread ? (blk % (8 * H)) / 8 : blk % H;
-    auto block_of = [&](uint32_t member) { return spread ? (c / 8) * 8 * H + member * 8 + c % 8 : c * H + member; };
+    const uint32_t bstride = spread ? 8u : 1u;   // block index distance of two neighbouring members
+    const uint32_t blk0 = blk - h * bstride;     // member 0 of this cluster
     const uint32_t k_lo = h * C, cnt = k_lo < N ? (N - k_lo < C ? N - k_lo : C) : 0u;   // host: cnt >= 1 for every member
     const bool has_left = h > 0, has_right = h + 1 < H;
 
     const DenseCtx<float, NCT, V> dc(wave, lane, cnt, k_lo);
-    const uint32_t row0 = (dc.live ? dc.kl : 0u) * n + dc.rp * V;    // first of this lane's rows, counted from knot k_lo
+    // first of this lane's rows, counted from knot k_lo: (wave * 9 + lane / 7) * 14 + (lane % 7) * 2 = wave * 126 + 2 * lane
+    const uint32_t row0 = dc.live ? wave * (Dg::BPW * n) + 2 * lane : 0u;
     const size_t grow0 = (size_t)k_lo * n + row0;                     // ... in the problem's vectors
-    const bool first_knot = dc.live && dc.kl == 0, last_knot = dc.live && dc.kl + 1 == cnt;
-    const uint32_t wl = (cnt - 1) / Dg::BPW;                          // the wave that owns the last knot
+    // the same index inside a window, from an opaque copy of the lane number (see GBDPCG_CL_HANDOFF: not worth a register)
+    auto own_idx = [&]() {
+        uint32_t lo = lane;
+        asm volatile("" : "+v"(lo));
+        return n + wave * (Dg::BPW * n) + 2 * lo;
+    };
+    const uint32_t wl = (cnt - 1) / Dg::BPW, lb = (cnt - 1) - wl * Dg::BPW;   // the last knot: wave wl, lanes [7 lb, 7 lb + 7)
     const uint32_t POLL = wl == 7 ? 6u : 7u;                          // the polling wave: never wave 0, never wave wl
     const size_t mstride = (size_t)3 * n * n * N;
 
@@ -90,22 +156,6 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     const __amdgpu_buffer_rsrc_t region =
         __builtin_amdgcn_make_buffer_rsrc(slots, 0, (int)(2u * grid * kClSlotBytes), 0x00020000);
     const uint32_t my_slot = blk * kClSlotBytes, par_stride = grid * kClSlotBytes;
-    // what this lane of the polling wave fetches in a gather (byte offset inside a parity's slots), if anything
-    uint32_t poll_off = 0;
-    bool poll_need = false;
-    if (lane < 4 * H) {
-        poll_off = block_of(lane / 4) * kClSlotBytes + (lane % 4) * 16;
-        poll_need = true;
-    } else if (lane >= kClLeftLane && lane < kClLeftLane + n / 2 && has_left) {
-        poll_off = block_of(h - 1) * kClSlotBytes + kClLastOff + (lane - kClLeftLane) * 16;
-        poll_need = true;
-    } else if (lane >= kClRightLane && lane < kClRightLane + n / 2 && has_right) {
-        poll_off = block_of(h + 1) * kClSlotBytes + kClFirstOff + (lane - kClRightLane) * 16;
-        poll_need = true;
-    }
-    // the halo entries of a window this lane of the polling wave rewrites after a gather
-    const bool halo_lane = poll_need && lane >= kClLeftLane;
-    const uint32_t halo_idx = lane >= kClRightLane ? (cnt + 1) * n + (lane - kClRightLane) * 2 : (lane - kClLeftLane) * 2;
 
     // LDS is workgroup-private and the hand-off stores must not be waited for: a barrier that drains only the LDS counter
 #ifdef GBDPCG_CL_SYNCTHREADS   // diagnostic variant: the full barrier (also waits for the hand-off stores)
@@ -116,23 +166,48 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 
     // One hand-off.  Every wave publishes its share PART of the inner product; the lanes that own the first / last knot
     // publish the two values V0, V1 of their rows.  The polling wave then gathers the 8H partials and the neighbours'
-    // boundary knots: TOTAL (wave-uniform, the same bits in every member) and, in its halo lanes, G0 / G1.
-#define GBDPCG_CL_HANDOFF(EPOCH, PART, V0, V1, TOTAL, G0, G1, OK)                                                   \
+    // boundary knots: TOTAL (wave-uniform, the same bits in every member) and, in its halo lanes, G0 / G1; HIDX = the
+    // entry of window HWIN a halo lane rewrites afterwards (0xffffffff: not a halo lane), H0 / H1 its current content.
+    // What a lane does follows from its lane number alone; it is recomputed here from an opaque copy of it, every time:
+    // kept in registers across the products (168 of 256 VGPRs hold matrix data) these few values were spilled, and each
+    // reload from scratch sat, with its s_waitcnt vmcnt(0), in front of the very stores the neighbour is waiting for.
+#define GBDPCG_CL_HANDOFF(EPOCH, PART, V0, V1, HWIN, TOTAL, G0, G1, H0, H1, HIDX, OK)                               \
     {                                                                                                                \
         const uint32_t tag = (EPOCH), par_off = (tag & 1u) * par_stride;                                             \
+        uint32_t lo = lane;                                                                                          \
+        asm volatile("" : "+v"(lo));                                                                                 \
         if (blk != drop_block) {                                                                                     \
-            if (lane == 0) {                                                                                         \
+            if (lo == 0) {                                                                                           \
                 const cl_u32x2 x = {fbits(PART), tag};                                                               \
                 __builtin_amdgcn_raw_buffer_store_b64(x, region, (int)(par_off + my_slot + wave * 8), 0, kClSc1);    \
             }                                                                                                        \
             const cl_u32x4 bx = {fbits(V0), tag, fbits(V1), tag};                                                    \
-            if (first_knot && has_left)                                                                              \
-                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClFirstOff + dc.rp * 16), 0, kClSc1); \
-            if (last_knot && has_right)                                                                              \
-                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClLastOff + dc.rp * 16), 0, kClSc1);  \
+            if (wave == 0 && has_left && lo < n / 2)                                                                 \
+                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClFirstOff + lo * 16), 0, kClSc1); \
+            if (wave == wl && has_right && lo - lb * (n / 2) < n / 2)                                                \
+                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClLastOff + (lo - lb * (n / 2)) * 16), 0, kClSc1); \
         }                                                                                                            \
-        if (wave == POLL) {                                                                                          \
-            bool have = !poll_need;                                                                                  \
+        if (wave == POLL) {                                                                    \
+            uint32_t poll_off = 0;                                                                                   \
+            bool have = true;                                                                                        \
+            HIDX = 0xffffffffu;                                                                                      \
+            if (lo < 4 * H) {                                                                                        \
+                poll_off = (blk0 + (lo >> 2) * bstride) * kClSlotBytes + (lo & 3u) * 16;                             \
+                have = false;                                                                                        \
+            } else if (lo - kClLeftLane < n / 2 && has_left) {                                                       \
+                poll_off = (blk - bstride) * kClSlotBytes + kClLastOff + (lo - kClLeftLane) * 16;                    \
+                HIDX = (lo - kClLeftLane) * 2;                                                                       \
+                have = false;                                                                                        \
+            } else if (lo - kClRightLane < n / 2 && has_right) {                                                     \
+                poll_off = (blk + bstride) * kClSlotBytes + kClFirstOff + (lo - kClRightLane) * 16;                  \
+                HIDX = (cnt + 1) * n + (lo - kClRightLane) * 2;                                                      \
+                have = false;                                                                                        \
+            }                                                                                                        \
+            /* the halo entries this lane is going to update: read now, under the wait */                           \
+            if (HIDX != 0xffffffffu) {                                                                               \
+                H0 = (HWIN)[HIDX];                                                                                   \
+                H1 = (HWIN)[HIDX + 1];                                                                               \
+            }                                                                                                        \
             cl_u32x4 got = {0u, 0u, 0u, 0u};                                                                         \
             OK = true;                                                                                               \
             for (uint32_t spins = 0;; ++spins) {                                                                     \
@@ -153,9 +228,18 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             const uint32_t gx = got.x, gz = got.z;                                                                   \
             G0 = __builtin_bit_cast(float, gx);                                                                      \
             G1 = __builtin_bit_cast(float, gz);                                                                      \
-            TOTAL = wave_sum(lane < 4 * H ? G0 + G1 : 0.f);                                                          \
+            TOTAL = wave_sum(lo < 4 * H ? G0 + G1 : 0.f);                                                            \
         }                                                                                                            \
     }
+
+    // Diagnostic build only (-DGBDPCG_CL_STAMPS, tools/cluster_stamps.py): cycle stamps of iteration 3 of the first problem
+    // of block 0, left in the unused words of the control block.  No stamp exists in the shipped build.
+#ifdef GBDPCG_CL_STAMPS
+#define GBDPCG_CL_STAMP(IDX, WAVE, COND)                                                                             \
+    if (blk == 0 && wave == (WAVE) && lane == 0 && (COND)) reinterpret_cast<u64 *>(ws)[IDX] = __builtin_amdgcn_s_memtime();
+#else
+#define GBDPCG_CL_STAMP(IDX, WAVE, COND)
+#endif
 
     uint32_t published = 0;   // did this workgroup write any slot?  (the last finisher clears them only if someone did)
     bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are reported, not solved
@@ -171,51 +255,117 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
             continue;
         }
+        GBDPCG_CL_STAMP(14, 0, ordinal == 1)
         published = 1;
         const uint32_t e0 = ordinal * epochs_per_problem;   // epochs e0 + 1 .. e0 + 2 max_iter + 2 belong to this problem
         const float *S = a.S + prob * mstride;
         const float *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;   // nullptr: identity preconditioner
         const size_t voff = (size_t)prob * len;
 
-        DenseTile<float, NCT, V> tS, tP;
-        dense_load<float, NCT, V>(S, N, dc, tS);
-        if (P) dense_load<float, NCT, V>(P, N, dc, tP);
-
-        float lamv[V], rv[V], pv[V], yv[V];
+        // lambda and gamma of this lane's rows and the two halo knots of lambda (straight from the input vector: no member
+        // writes lambda before every member has passed its first hand-off) are requested BEFORE the tiles, so that their
+        // round trips run under the 300 KB of tile loads instead of in front of the first product
+        float lamv[V], gamv[V], halo_lam = 0.f;
 #pragma unroll
-        for (int j = 0; j < V; ++j) lamv[j] = dc.live ? a.lambda[voff + grow0 + j] : 0.f;
-        // windows: zero everywhere (rows past the own knots, halos at the ends of the problem), then lambda with its halos
-        // straight from the input vector (no member writes lambda before every member has passed its first hand-off)
-        for (uint32_t i = tid; i < WINF; i += THREADS) {
-            const int64_t gi = (int64_t)k_lo * n - n + i;
-            xa[i] = (i < (cnt + 2) * n && gi >= 0 && gi < (int64_t)len) ? a.lambda[voff + gi] : 0.f;
+        for (int j = 0; j < V; ++j) {
+            lamv[j] = dc.live ? a.lambda[voff + grow0 + j] : 0.f;
+            gamv[j] = dc.live ? a.gamma[voff + grow0 + j] : 0.f;
+        }
+        if (tid < 2 * n) {   // threads [0, n): the knot before the own ones, [n, 2n): the knot after them
+            const int64_t gi = tid < n ? (int64_t)k_lo * n - n + tid : (int64_t)(k_lo + cnt) * n + (tid - n);
+            if (gi >= 0 && gi < (int64_t)len) halo_lam = a.lambda[voff + gi];
+        }
+
+        DenseTile<float, NCT, V> tS, tP;
+        if constexpr (STAGED) {
+            GBDPCG_CL_STAMP(12, 0, ordinal == 0)
+            // this wave's knots [kw, kw + nk) and, per instruction of a stage, the byte offset of this lane's piece from the
+            // first of them (lanes beyond the last piece re-read piece 0 into slots nobody picks up: every lane of every
+            // instruction is live, so a stage is always exactly 7 loads on the wave's counter)
+            const uint32_t kw = k_lo + wave * Dg::BPW;
+            const uint32_t nk = wave * Dg::BPW < cnt ? (cnt - wave * Dg::BPW < Dg::BPW ? cnt - wave * Dg::BPW : Dg::BPW) : 0u;
+            const uint32_t kbase = kw < N ? kw : N - 1;
+            uint32_t rel[7];
+#pragma unroll
+            for (uint32_t i = 0; i < 7; ++i) {
+                const uint32_t q = i * 64 + lane, j = q / kClPieces, piece = q - j * kClPieces;
+                rel[i] = j < nk ? j * (3 * n * n * 4) + piece * 16 : 0u;
+            }
+            float *buf0 = reinterpret_cast<float *>(stage_raw) + wave * kClStageFloats;
+            float *buf1 = buf0 + Dg::WAVES * kClStageFloats;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)buf0, lds1 = (uint32_t)(uintptr_t)buf1;
+            const float *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
+            const uint32_t b9 = dc.live ? lane / Dg::LPB : 0u;
+            // six stages (S: L D R, Pinv: L D R), two in flight, alternating buffers
+            cluster_stage_issue(Sw, rel, lds0);
+            cluster_stage_issue(Sw + n * n, rel, lds1);
+            cluster_stage_wait<1>();
+            cluster_stage_pick<NCT, V, 0>(buf0, dc, b9, N, tS);
+            cluster_stage_issue(Sw + 2 * n * n, rel, lds0);
+            cluster_stage_wait<1>();
+            cluster_stage_pick<NCT, V, 1>(buf1, dc, b9, N, tS);
+            if (P) cluster_stage_issue(Pw, rel, lds1);
+            if (P) cluster_stage_wait<1>(); else cluster_stage_wait<0>();
+            cluster_stage_pick<NCT, V, 2>(buf0, dc, b9, N, tS);
+            if (P) {
+                cluster_stage_issue(Pw + n * n, rel, lds0);
+                cluster_stage_wait<1>();
+                cluster_stage_pick<NCT, V, 0>(buf1, dc, b9, N, tP);
+                cluster_stage_issue(Pw + 2 * n * n, rel, lds1);
+                cluster_stage_wait<1>();
+                cluster_stage_pick<NCT, V, 1>(buf0, dc, b9, N, tP);
+                cluster_stage_wait<0>();
+                cluster_stage_pick<NCT, V, 2>(buf1, dc, b9, N, tP);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last picks are in registers before anything else happens
+            GBDPCG_CL_STAMP(13, 0, ordinal == 0)
+            GBDPCG_CL_STAMP(15, 0, ordinal == 1)
+        } else {
+            dense_load<float, NCT, V>(S, N, dc, tS);
+            if (P) dense_load<float, NCT, V>(P, N, dc, tP);
+        }
+
+        float rv[V], pv[V], yv[V];
+        // windows: lambda on the own knots and the halos, zeros behind them (rows past the own knots, halos at the ends
+        // of the problem); every entry has exactly one writer
+        if (dc.live) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) xa[n + row0 + j] = lamv[j];
+        }
+        if (tid < 2 * n) {
+            const uint32_t i = tid < n ? tid : (cnt + 1) * n + (tid - n);
+            xa[i] = halo_lam;
             xb[i] = 0.f;
         }
+        for (uint32_t i = (cnt + 2) * n + tid; i < WINF; i += THREADS) xa[i] = xb[i] = 0.f;
         if (tid == 0) bci[0] = 0u;
         wg_barrier();
+        GBDPCG_CL_STAMP(16, 0, ordinal == 1)
 
-        float total = 0.f, g0 = 0.f, g1 = 0.f, part;
+        float total = 0.f, g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f, part;
+        uint32_t hidx = 0xffffffffu;
         bool ok = true;
         // r = gamma - S lambda                                            (pcg.cuh:118-126); the boundary knots of r travel
-        dense_mv<float, NCT, V>(tS, xa, dc, yv);
+        dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tS, xa, dc, yv);
 #pragma unroll
-        for (int j = 0; j < V; ++j) rv[j] = dc.live ? a.gamma[voff + grow0 + j] - yv[j] : 0.f;
+        for (int j = 0; j < V; ++j) rv[j] = dc.live ? gamv[j] - yv[j] : 0.f;
         if (dc.live) {
 #pragma unroll
             for (int j = 0; j < V; ++j) xb[n + row0 + j] = rv[j];
         }
-        GBDPCG_CL_HANDOFF(e0 + 1u, 0.f, rv[0], rv[1], total, g0, g1, ok)
+        GBDPCG_CL_HANDOFF(e0 + 1u, 0.f, rv[0], rv[1], xb, total, g0, g1, h0, h1, hidx, ok)
         if (wave == POLL) {
             if (!ok && lane == 0) bci[0] = 2u;
-            if (ok && halo_lane) { xb[halo_idx] = g0; xb[halo_idx + 1] = g1; }
+            if (ok && hidx != 0xffffffffu) { xb[hidx] = g0; xb[hidx + 1] = g1; }
         }
         wg_barrier();
         bool failed = bci[0] == 2u;
+        GBDPCG_CL_STAMP(17, 0, ordinal == 1)
 
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
         float eta = 0.f;
         if (!failed) {
-            if (P) dense_mv<float, NCT, V>(tP, xb, dc, yv);
+            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tP, xb, dc, yv);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -227,29 +377,36 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #pragma unroll
                 for (int j = 0; j < V; ++j) xa[n + row0 + j] = pv[j];
             }
-            GBDPCG_CL_HANDOFF(e0 + 2u, part, pv[0], pv[1], total, g0, g1, ok)
+            GBDPCG_CL_HANDOFF(e0 + 2u, part, pv[0], pv[1], xa, total, g0, g1, h0, h1, hidx, ok)
             if (wave == POLL) {
                 if (lane == 0) {
                     if (!ok) bci[0] = 2u;
                     bc[0] = total;
                 }
-                if (ok && halo_lane) { xa[halo_idx] = g0; xa[halo_idx + 1] = g1; }
+                if (ok && hidx != 0xffffffffu) { xa[hidx] = g0; xa[hidx + 1] = g1; }
             }
             wg_barrier();
             failed = bci[0] == 2u;
             eta = bc[0];
         }
 
+        GBDPCG_CL_STAMP(18, 0, ordinal == 1)
         uint32_t iter = 0;
         bool max_iter_exit = true;
         for (; !failed && iter < a.max_iter; ++iter) {                    // pcg.cuh:154
             // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
-            dense_mv<float, NCT, V>(tS, xa, dc, yv);
+            GBDPCG_CL_STAMP(1, POLL, iter == 3 && ordinal == 0)
+            GBDPCG_CL_STAMP(8, 0, iter == 3 && ordinal == 0)
+            dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tS, xa, dc, yv);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) part = fma_t(pv[j], yv[j], part);
             part = wave_sum(part);
-            GBDPCG_CL_HANDOFF(e0 + 3u + 2u * iter, part, yv[0], yv[1], total, g0, g1, ok)
+            GBDPCG_CL_STAMP(2, POLL, iter == 3 && ordinal == 0)
+            GBDPCG_CL_STAMP(9, 0, iter == 3 && ordinal == 0)
+            GBDPCG_CL_HANDOFF(e0 + 3u + 2u * iter, part, yv[0], yv[1], xb, total, g0, g1, h0, h1, hidx, ok)
+            GBDPCG_CL_STAMP(3, POLL, iter == 3 && ordinal == 0)
+            GBDPCG_CL_STAMP(10, 0, iter == 3 && ordinal == 0)
             if (wave == POLL) {
                 const float al = eta / total;
                 if (lane == 0) {
@@ -257,12 +414,13 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                     bc[0] = al;
                 }
                 // r -= alpha upsilon on the halo knots: the owner's fma on the owner's bits
-                if (ok && halo_lane) {
-                    xb[halo_idx] = fma_t(-al, g0, xb[halo_idx]);
-                    xb[halo_idx + 1] = fma_t(-al, g1, xb[halo_idx + 1]);
+                if (ok && hidx != 0xffffffffu) {
+                    xb[hidx] = fma_t(-al, g0, h0);
+                    xb[hidx + 1] = fma_t(-al, g1, h1);
                 }
             }
             wg_barrier();
+            GBDPCG_CL_STAMP(4, POLL, iter == 3 && ordinal == 0)
             if (bci[0] == 2u) { failed = true; break; }
             const float alpha = bc[0];
             // lambda += alpha p ; r -= alpha upsilon                      (pcg.cuh:172-176)
@@ -271,13 +429,11 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 lamv[j] = fma_t(alpha, pv[j], lamv[j]);
                 rv[j] = fma_t(-alpha, yv[j], rv[j]);
             }
-            if (dc.live) {
-#pragma unroll
-                for (int j = 0; j < V; ++j) xb[n + row0 + j] = rv[j];
-            }
+            if (dc.live) *reinterpret_cast<float2 *>(xb + own_idx()) = make_float2(rv[0], rv[1]);
             wg_barrier();
+            GBDPCG_CL_STAMP(5, POLL, iter == 3 && ordinal == 0)
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            if (P) dense_mv<float, NCT, V>(tP, xb, dc, yv);
+            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tP, xb, dc, yv);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -285,7 +441,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 part = fma_t(rv[j], yv[j], part);
             }
             part = wave_sum(part);
-            GBDPCG_CL_HANDOFF(e0 + 4u + 2u * iter, part, yv[0], yv[1], total, g0, g1, ok)
+            GBDPCG_CL_HANDOFF(e0 + 4u + 2u * iter, part, yv[0], yv[1], xa, total, g0, g1, h0, h1, hidx, ok)
             if (wave == POLL) {
                 const bool conv = fabsf(total) < a.tol;                   // pcg.cuh:195
                 const float be = total / eta;                             // pcg.cuh:199
@@ -295,9 +451,9 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                     bc[1] = be;
                 }
                 // p = r~ + beta p on the halo knots                       (pcg.cuh:203-206)
-                if (ok && !conv && halo_lane) {
-                    xa[halo_idx] = fma_t(be, xa[halo_idx], g0);
-                    xa[halo_idx + 1] = fma_t(be, xa[halo_idx + 1], g1);
+                if (ok && !conv && hidx != 0xffffffffu) {
+                    xa[hidx] = fma_t(be, h0, g0);
+                    xa[hidx + 1] = fma_t(be, h1, g1);
                 }
             }
             wg_barrier();
@@ -308,17 +464,17 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 max_iter_exit = false;
                 break;
             }
+            GBDPCG_CL_STAMP(6, POLL, iter == 3 && ordinal == 0)
             const float beta = bc[1];
             eta = bc[0];
 #pragma unroll
             for (int j = 0; j < V; ++j) pv[j] = fma_t(beta, pv[j], yv[j]);
-            if (dc.live) {
-#pragma unroll
-                for (int j = 0; j < V; ++j) xa[n + row0 + j] = pv[j];
-            }
+            if (dc.live) *reinterpret_cast<float2 *>(xa + own_idx()) = make_float2(pv[0], pv[1]);
             wg_barrier();
+            GBDPCG_CL_STAMP(7, POLL, iter == 3 && ordinal == 0)
         }
 
+        GBDPCG_CL_STAMP(19, 0, ordinal == 1)
         // outputs                                                         (pcg.cuh:212,215)
         if (dc.live && !failed) {
 #pragma unroll
@@ -334,8 +490,10 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         }
         dead = failed;
         wg_barrier();   // the windows and bci are reused by the next problem
+        GBDPCG_CL_STAMP(20, 0, ordinal == 1)
     }
 #undef GBDPCG_CL_HANDOFF
+#undef GBDPCG_CL_STAMP
 
     // ---- leave the slots zeroed for the next launch --------------------------------------------------------------
     // Every wave drains its stores, the workgroup meets, one thread counts it in; the workgroup whose add comes last
@@ -395,8 +553,18 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
             const char *e = getenv("GBDPCG_CLUSTER_DROP_WG");
             return e ? (uint32_t)strtoul(e, nullptr, 10) : 0xffffffffu;
         }();
-        hipLaunchKernelGGL((pcg_cluster_kernel<14, 2>), dim3(clusters * H), dim3(512), 0, s, a,
-                           static_cast<unsigned char *>(a.cluster_ws), H, C, clusters, spin_limit, drop_block);
+        // coalesced LDS-DMA tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
+        static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
+        const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
+        auto kern = staged ? pcg_cluster_kernel<14, 2, true> : pcg_cluster_kernel<14, 2, false>;
+        const size_t lds = staged ? (size_t)2 * DenseGeom<float, 14, 2>::WAVES * kClStageBytes : 0;
+        // on every launch, like the other launchers: HIP keeps the attribute per device
+        if (lds) {
+            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (*err != hipSuccess) return true;
+        }
+        hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, a, static_cast<unsigned char *>(a.cluster_ws), H, C,
+                           clusters, spin_limit, drop_block);
         *err = hipGetLastError();
         return true;
     } else {
