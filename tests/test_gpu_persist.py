@@ -189,7 +189,10 @@ def test_persistent_state_size_14(solver, orc, path, dtype, N, B):
 
 
 def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
-    assert solver.choose_path(4, 14, 256, 1) == binding.PATH_PERSISTENT      # 1.2 MB per iteration through one CU otherwise
+    assert solver.choose_path(8, 14, 256, 1) == binding.PATH_PERSISTENT      # 2.4 MB per iteration through one CU otherwise
+    # fp32: four CUs keep it resident on the cluster path (3.7 us per iteration against 4.7 here, tools/ab_cluster.py 256 1)
+    assert solver.choose_path(4, 14, 256, 1) == binding.PATH_FUSED and solver.cluster_members(4, 14, 256) == 4
+    assert solver.choose_path(4, 14, 300, 1) == binding.PATH_PERSISTENT      # beyond four CUs' worth of knots
     assert solver.choose_path(4, 14, 128, 1) == binding.PATH_FUSED           # symmetric halves resident on one CU (default mode 2)
     assert solver.choose_path(4, 14, 64, 1) == binding.PATH_FUSED            # register-resident
     assert solver.choose_path(4, 14, 256, 64) == binding.PATH_FUSED or solver.choose_path(4, 14, 256, 64) == binding.PATH_SPLIT
