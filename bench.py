@@ -87,6 +87,49 @@ def pcg_flops_per_launch(n, N, batch, iters):
     return batch * (2 * iters + 2) * 2 * (3 * N - 2) * n * n
 
 
+STREAMING_CHILD = r"""
+import sys, json, torch
+sys.path.insert(0, sys.argv[1])
+from gbd_pcg_amd import binding, synth
+n, N, B, iters = (int(v) for v in sys.argv[2:6])
+s = binding.Solver(0)
+g = synth.gen_torch_seeded(n, N, 0, B, "cuda", torch.float32)
+S, gamma = g["S"], g["gamma"]
+P = s.form_pinv(n, N, B, S, binding.PINV_STAIR)
+lam = torch.zeros_like(gamma); it = torch.zeros(B, dtype=torch.int32, device="cuda"); fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+s.set_symmetric(0)
+gr = s.graph_solve(n, N, B, S, P, gamma, lam, None, None, 0.0, iters, it, fl)
+for _ in range(5): lam.zero_(); gr.launch()
+evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+torch.cuda.synchronize()
+for a, b in evs: a.record(); gr.launch(); b.record()
+torch.cuda.synchronize()
+t = sorted(a.elapsed_time(b) for a, b in evs)
+print(json.dumps({"kernel_ms": t[15]}))
+"""
+
+
+def time_streaming_general(n, N, B, iters):
+    """pcg_fused_kernel<float,14,2,8,false> (both matrices streamed every iteration) on the same workload, in a child
+    process with the cluster path switched off; None if the child fails."""
+    import subprocess
+    env = dict(os.environ, GBDPCG_NO_CLUSTER="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        o = subprocess.run([sys.executable, "-c", STREAMING_CHILD, os.path.dirname(os.path.abspath(__file__)), str(n), str(N),
+                            str(B), str(iters)], env=env, capture_output=True, text=True, timeout=180)
+        line = [ln for ln in o.stdout.splitlines() if ln.startswith("{")]
+        ms = json.loads(line[-1])["kernel_ms"]
+    except Exception:
+        return None
+    by = pcg_bytes_per_launch(n, N, B, iters, 4)
+    return {"kernel": "pcg_fused_kernel<float,14,2,8,false> (GBDPCG_NO_CLUSTER=1)", "kernel_ms": ms,
+            "problem_iters_per_sec_one_gpu": B * iters / (ms * 1e-3), "algorithmic_GBps": by / (ms * 1e-3) / 1e9,
+            "note": "algorithmic bytes / time; the in-flight set is re-read every iteration, so part is served by the 256 MiB "
+                    "Infinity Cache: not an HBM-only statement"}
+
+
 def pcg_bytes_per_launch(n, N, batch, iters, s):
     """Algorithmic HBM bytes of one solve by SURVEY.md section 8d: S and Pinv streamed once per iteration
     (2 (3N-2) n^2 s) + the prologue's one pass over each + vectors (gamma, lambda in; lambda, r, p out)."""
@@ -375,15 +418,29 @@ def run_rank(args, world, rank, local_rank):
         }
 
     if world == 1:
-        gen_ms, _ = time_mode(0, 30)        # general kernel (always reads L): the reference-equivalent stream
-        gen_gbps = pcg_bytes / (gen_ms * 1e-3) / 1e9
+        # General (not bit-symmetric) storage: gbdpcg_set_symmetric(0) makes every problem take the path a caller-formed
+        # Phi^-1 takes.  Since round 2 that is the cluster kernel (both matrices register-resident over two CUs per
+        # problem, two cross-CU hand-offs per iteration); the kernel that streams both matrices every iteration is timed in
+        # a child process with GBDPCG_NO_CLUSTER=1 (the switch is read once per process).
+        gen_ms, gen_best = time_mode(0, 60)
+        gen_tflops = flops / (gen_ms * 1e-3) / 1e12
+        full_bytes = B * (2 * 3 * N * n * n + 5 * n * N) * 4      # [L|D|R] of both matrices once per solve + vectors
+        clusters = 256 // 2
+        rounds = -(-B // clusters)
         out["general_kernel"] = {
-            "kernel": "pcg_fused_kernel<float,14,2,8,false> (gbdpcg_set_symmetric(0): always reads L)",
-            "bound": "hbm+mall", "achieved": gen_gbps, "unit": "GB/s", "frac": gen_gbps / HBM_PEAK_GBPS, "kernel_ms": gen_ms,
-            "traffic": pmc_traffic("pcg_fused_kernel<float,14,2,8,false>"),
+            "kernel": "pcg_cluster_kernel<14,2,true> (gbdpcg_set_symmetric(0): general storage, two CUs per problem)",
+            "bound": "latency", "achieved": gen_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": gen_tflops / FP32_VECTOR_PEAK_TFLOPS, "kernel_ms": gen_ms, "kernel_ms_min": gen_best,
+            "traffic": pmc_traffic("pcg_cluster_kernel"),
             "problem_iters_per_sec_one_gpu": B * iters / (gen_ms * 1e-3),
-            "note": "algorithmic bytes / time; the in-flight set is re-read every iteration, so part is served by the "
-                    "256 MiB Infinity Cache: not an HBM-only statement"}
+            "us_per_iteration_of_a_cluster": gen_ms * 1e3 / rounds / (iters + 1),
+            "handoff_floor_us_per_iteration": 2 * 0.5,
+            "hbm_share": {"bytes_moved_per_launch": full_bytes, "achieved_GBps": full_bytes / (gen_ms * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": full_bytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "streaming_kernel": time_streaming_general(n, N, B, iters),
+            "note": "the matrices are read once per solve; an iteration is two products (LDS-read bound) and two hand-offs "
+                    "between the two workgroups of a problem (0.44-0.56 us each, tools/hop_probe.hip): the bound is that "
+                    "latency, not HBM and not the VALU; us_per_iteration_of_a_cluster includes the tile loads (upper bound)"}
 
         # standalone SpMV over FOUR distinct 308 MB matrices in rotation (1.23 GB: the 256 MiB Infinity Cache
         # cannot hold anything between two uses of the same line), each launch bracketed by its own event pair
