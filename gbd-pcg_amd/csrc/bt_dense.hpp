@@ -72,13 +72,17 @@ __device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, 
 // accumulator per block, y = (L x_{k-1} + D x_k) + R x_{k+1}, each block's columns ascending: three independent chains of
 // 14 packed fma's instead of one of 42 (a dependent v_pk_fma_f32 issues every ~10 cycles: the single chain cost
 // ~1,000 cycles per product with two waves per SIMD, measured in pcg_cluster.hip).
-template <typename T, int NCT, int V, int CHAINS = 1>
+// TAIL > 0 (CHAINS = 3 only): the last TAIL columns of the block-row are not in the tile but in LDS, `tail[t * tstride]` =
+// this lane's two rows of column COLS - TAIL + t (a deliberate, cheap spill: pcg_cluster.hip keeps 8 of its 168 matrix
+// registers there, because hipcc otherwise spills a few of them to scratch and reloads them inside every product).
+template <typename T, int NCT, int V, int CHAINS = 1, int TAIL = 0>
 __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T *X, const DenseCtx<T, NCT, V> &dc,
-                                         T (&acc)[V])
+                                         T (&acc)[V], const typename VecOf<T, 2>::type *tail = nullptr, uint32_t tstride = 0)
 {
     using Dg = DenseGeom<T, NCT, V>;
     using P2 = typename VecOf<T, 2>::type;
     static_assert(CHAINS == 1 || (CHAINS == 3 && Dg::N_ % 2 == 0), "one chain, or one per block (whole x pairs per block)");
+    static_assert(TAIL == 0 || (CHAINS == 3 && V == 2 && TAIL % 2 == 0 && TAIL <= (int)Dg::N_), "tail columns: whole pairs of the last block");
     const uint32_t kl = dc.live ? dc.kl : 0u;
     const P2 *xk = reinterpret_cast<const P2 *>(X + kl * Dg::N_);  // column c of local row kl multiplies X[kl*n + c]
     T part[CHAINS][V];
@@ -98,16 +102,47 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = part[0][j];
     } else {
+        // The three blocks side by side: independent work in every step.  The steps are pinned in source order with the
+        // operands of the next one requested before the fma's of this one: left to itself hipcc hoists all 21 operand reads
+        // to the top (42 more live registers next to 168 of matrix data) and spills elsewhere in the kernel.
+        P2 xv[3], nx[3], tv[2], nt[2];
 #pragma unroll
-        for (uint32_t c = 0; c < Dg::N_; c += 2) {   // the three blocks side by side: independent work in every step
+        for (int q = 0; q < 3; ++q) xv[q] = xk[(q * Dg::N_) / 2];
+        if constexpr (TAIL >= (int)Dg::N_) {
+            tv[0] = tail[0];
+            tv[1] = tail[tstride];
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < Dg::N_; c += 2) {
+            if (c + 2 < Dg::N_) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) nx[q] = xk[(q * Dg::N_ + c + 2) / 2];
+                if constexpr (TAIL > 0) {
+                    if (c + 2 >= Dg::N_ - TAIL) {   // the next step's two columns of the last block come from LDS
+                        nt[0] = tail[(c + 2 - (Dg::N_ - TAIL)) * tstride];
+                        nt[1] = tail[(c + 3 - (Dg::N_ - TAIL)) * tstride];
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const P2 xv = xk[(q * Dg::N_ + c) / 2];
+                const bool from_lds = TAIL > 0 && q == 2 && c >= Dg::N_ - TAIL;
 #pragma unroll
-                for (int j = 0; j < V; ++j) part[q][j] = fma_t(tl.a[q * Dg::N_ + c][j], xv.x, part[q][j]);
+                for (int j = 0; j < V; ++j) {
+                    const T m = from_lds ? (j == 0 ? tv[0].x : tv[0].y) : tl.a[q * Dg::N_ + c][j];
+                    part[q][j] = fma_t(m, xv[q].x, part[q][j]);
+                }
 #pragma unroll
-                for (int j = 0; j < V; ++j) part[q][j] = fma_t(tl.a[q * Dg::N_ + c + 1][j], xv.y, part[q][j]);
+                for (int j = 0; j < V; ++j) {
+                    const T m = from_lds ? (j == 0 ? tv[1].x : tv[1].y) : tl.a[q * Dg::N_ + c + 1][j];
+                    part[q][j] = fma_t(m, xv[q].y, part[q][j]);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xv[q] = nx[q];
+            tv[0] = nt[0];
+            tv[1] = nt[1];
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = (part[0][j] + part[1][j]) + part[2][j];

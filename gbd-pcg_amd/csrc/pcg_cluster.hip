@@ -17,12 +17,22 @@
 // (MI355X_MICROARCH.md, Valid forms, R2; the same protocol as pcg_persist.hip).  One such hand-off between two CUs costs
 // 0.44-0.56 us (tools/hop_probe.hip), against 1.4-2 us for the chip-wide all-gather of the persistent path.
 //
-// Epochs start at 1 in every launch and slots hold 0 between launches: the workgroup that finishes LAST (an agent-scope
-// counter tells it) clears the slots once every other workgroup has drained its stores, so nothing has to be initialised
-// by a launch of its own and a solve stays ONE kernel node in a hipGraph.  A cluster's workgroups must be resident
-// together: the grid never exceeds one workgroup per CU, members of a cluster have neighbouring block indices (in-order
-// dispatch then splits at most one cluster at a time, and that one only until any workgroup exits), and every spin is
-// bounded: a cluster that cannot complete a hand-off reports max_iter_exit = 2, iters = 0xffffffff for its problems.
+// Epochs start at 1 in every launch and nothing is initialised by a launch of its own (a solve stays ONE kernel node in a
+// hipGraph): a slot is only ever written by the workgroup that owns it.  Before its first problem a cluster says HELLO
+// (epoch 1: every member publishes the id of the XCD it runs on); after its last one it says FIN (an epoch above all the
+// others).  A member that has gathered FIN knows that every member has consumed everything older, zeroes its slots of the
+// OTHER parity and leaves the FIN tag in this one: the first epochs a later launch polls for in a slot are 1 and 2, FIN is
+// at least 6, and by the time a launch asks a slot for epoch e its owner has rewritten it with e - 2.  (The first form
+// -- the workgroup that finishes last zeroes all slots -- wrote lines from one XCD that another XCD had written, which
+// rules out the plain stores below.)
+// When HELLO shows every member of a cluster on the SAME XCD (members sit 8 blocks apart for that, under round-robin
+// dispatch) the cluster publishes with PLAIN stores: the line stays in the XCD's L2, where the partner's sc1 loads find
+// it -- 0.25 us per hand-off instead of 0.44 (tools/hop_probe.hip; across XCDs a plain store is never seen, hence the
+// check).  Otherwise, and always across XCDs, stores are sc1 (write-through).  Nothing depends on placement.
+// A cluster's workgroups must be resident together: the grid never exceeds one workgroup per CU, members of a cluster have
+// neighbouring block indices (in-order dispatch then splits at most one cluster at a time, and that one only until any
+// workgroup exits), and every spin is bounded: a cluster that cannot complete a hand-off reports max_iter_exit = 2,
+// iters = 0xffffffff for its problems and zeroes its own slots.
 #include <cstdlib>
 
 #include "bt_dense.hpp"
@@ -38,7 +48,7 @@ typedef unsigned int cl_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on gfx950: bit 4 = sc1
 
-// Workspace: [256-byte control block | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
+// Workspace: [256-byte block (stamps of the diagnostic build) | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
 //   +0    the 8 wave partials (8 granules)
 //   +128  the first own knot of the product vector, for the left neighbour  (n granules, two per 16-byte store)
 //   +256  the last own knot, for the right neighbour
@@ -51,6 +61,9 @@ __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(u
 // 2 (L % 4), +1), lanes [32, 39) the left neighbour's last knot, lanes [40, 47) the right neighbour's first knot.
 constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
 
+#ifndef GBDPCG_CL_PTAIL
+#define GBDPCG_CL_PTAIL 0   // columns of a lane's Pinv block-row kept in LDS instead of registers (0, 2, 4, ...): not needed since the kernel compiles without scratch; kept for A/B builds
+#endif
 #ifndef GBDPCG_CL_CHAINS
 #define GBDPCG_CL_CHAINS 3   // accumulator chains of a block-row product (bt_dense.hpp, dense_mv); 1 for A/B builds
 #endif
@@ -63,11 +76,23 @@ constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
 constexpr uint32_t kClStageChunks = 7 * 64, kClStageBytes = kClStageChunks * 16, kClStageFloats = kClStageBytes / 4;
 constexpr uint32_t kClPieces = 49;   // 16-byte pieces per n x n block, n = 14
 
-// Issue one stage: lane l of instruction i moves 16 bytes from base + rel[i] to lds_addr + i * 1024 + l * 16.  The loads
-// are written in asm (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with
-// cluster_stage_wait before it reads the buffer, and never has more than two stages in flight.
-__device__ __forceinline__ void cluster_stage_issue(const float *base, const uint32_t (&rel)[7], uint32_t lds_addr)
+// Issue one stage: lane l of instruction i moves the 16-byte piece q = 64 i + l of the wave's `nk` blocks (49 pieces each, blocks
+// 3 n^2 floats apart) from base to lds_addr + 16 q.  Lanes beyond the last piece re-read piece 0 into slots nobody picks
+// up: every lane of every instruction is live, so a stage is always exactly 7 loads on the wave's counter.  The offsets
+// are recomputed from the lane number at every issue (kept in registers across the stages they were spilled, and every
+// reload from scratch came with an s_waitcnt vmcnt(0) that drained the stages in flight).  The loads are written in asm
+// (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with cluster_stage_wait before
+// it reads the buffer, and never has more than two stages in flight.
+__device__ __forceinline__ void cluster_stage_issue(const float *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
 {
+    uint32_t lo = lane;
+    asm volatile("" : "+v"(lo));
+    uint32_t rel[7];
+#pragma unroll
+    for (uint32_t i = 0; i < 7; ++i) {
+        const uint32_t q = i * 64 + lo, j = (q * 1338u) >> 16;   // q / 49 for q < 448
+        rel[i] = j < nk ? q * 16 + j * (3 * 14 * 14 * 4 - kClPieces * 16) : 0u;
+    }
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
@@ -122,6 +147,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     __shared__ __attribute__((aligned(16))) float xb[WINF];   // window of r
     __shared__ float bc[4];       // [0] alpha / eta' of the phase just gathered, [1] beta
     __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out
+    // the last GBDPCG_CL_PTAIL columns of this lane's block-row of Pinv (two rows each): see dense_mv, TAIL
+    __shared__ __attribute__((aligned(16))) float2 ptail[(GBDPCG_CL_PTAIL ? GBDPCG_CL_PTAIL : 1) * THREADS];
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: [2][8 waves][kClStageBytes]
 
     const uint32_t N = a.N, len = n * N;
@@ -177,15 +204,20 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         uint32_t lo = lane;                                                                                          \
         asm volatile("" : "+v"(lo));                                                                                 \
         if (blk != drop_block) {                                                                                     \
-            if (lo == 0) {                                                                                           \
-                const cl_u32x2 x = {fbits(PART), tag};                                                               \
-                __builtin_amdgcn_raw_buffer_store_b64(x, region, (int)(par_off + my_slot + wave * 8), 0, kClSc1);    \
-            }                                                                                                        \
+            const cl_u32x2 x = {fbits(PART), tag};                                                                   \
             const cl_u32x4 bx = {fbits(V0), tag, fbits(V1), tag};                                                    \
-            if (wave == 0 && has_left && lo < n / 2)                                                                 \
-                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClFirstOff + lo * 16), 0, kClSc1); \
-            if (wave == wl && has_right && lo - lb * (n / 2) < n / 2)                                                \
-                __builtin_amdgcn_raw_buffer_store_b128(bx, region, (int)(par_off + my_slot + kClLastOff + (lo - lb * (n / 2)) * 16), 0, kClSc1); \
+            const int o_part = (int)(par_off + my_slot + wave * 8), o_first = (int)(par_off + my_slot + kClFirstOff + lo * 16), \
+                      o_last = (int)(par_off + my_slot + kClLastOff + (lo - lb * (n / 2)) * 16);                     \
+            const bool p_first = wave == 0 && has_left && lo < n / 2, p_last = wave == wl && has_right && lo - lb * (n / 2) < n / 2; \
+            if (same_xcd) {   /* plain: the line stays in this XCD's L2, where every member of the cluster polls */   \
+                if (lo == 0) __builtin_amdgcn_raw_buffer_store_b64(x, region, o_part, 0, 0);                         \
+                if (p_first) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_first, 0, 0);                      \
+                if (p_last) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_last, 0, 0);                        \
+            } else {          /* sc1: write-through, seen from any XCD */                                            \
+                if (lo == 0) __builtin_amdgcn_raw_buffer_store_b64(x, region, o_part, 0, kClSc1);                    \
+                if (p_first) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_first, 0, kClSc1);                 \
+                if (p_last) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_last, 0, kClSc1);                   \
+            }                                                                                                        \
         }                                                                                                            \
         if (wave == POLL) {                                                                    \
             uint32_t poll_off = 0;                                                                                   \
@@ -237,15 +269,29 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #ifdef GBDPCG_CL_STAMPS
 #define GBDPCG_CL_STAMP(IDX, WAVE, COND)                                                                             \
     if (blk == 0 && wave == (WAVE) && lane == 0 && (COND)) reinterpret_cast<u64 *>(ws)[IDX] = __builtin_amdgcn_s_memtime();
+// ... and the 100 MHz real-time clock (wall time, whatever the shader clock does) for the problem-level stamps
+#define GBDPCG_CL_STAMP_RT(IDX, WAVE, COND)                                                                          \
+    if (blk == 0 && wave == (WAVE) && lane == 0 && (COND)) reinterpret_cast<u64 *>(ws)[IDX] = __builtin_amdgcn_s_memrealtime();
+// start (0) / end (1) of every workgroup, behind the slots as sized for the device (256 CUs on the MI355X)
+#define GBDPCG_CL_STAMP_WG(WHICH)                                                                                    \
+    if (tid == 0) reinterpret_cast<u64 *>(ws + kClCtrlBytes + 2u * 256u * kClSlotBytes)[2 * blk + (WHICH)] = __builtin_amdgcn_s_memrealtime();
 #else
+#define GBDPCG_CL_STAMP_WG(WHICH)
 #define GBDPCG_CL_STAMP(IDX, WAVE, COND)
+#define GBDPCG_CL_STAMP_RT(IDX, WAVE, COND)
 #endif
 
-    uint32_t published = 0;   // did this workgroup write any slot?  (the last finisher clears them only if someone did)
+    bool greeted = false;     // HELLO done: this workgroup has written slots (and owes a FIN)
+    bool same_xcd = false;    // every member of the cluster runs on this XCD: publish with plain stores (set by HELLO)
     bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are reported, not solved
     uint32_t ordinal = 0;     // problems of this cluster so far: the epochs of a problem continue where the last one stopped
     const uint32_t epochs_per_problem = 2u * a.max_iter + 4u;
+    uint32_t xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    xcc_id = (xcc_id & 0xfu) + 1u;   // never 0: a payload of its own kind
 
+    GBDPCG_CL_STAMP_RT(21, 0, true)
+    GBDPCG_CL_STAMP_WG(0)
     for (uint32_t prob = c; prob < a.batch; prob += clusters, ++ordinal) {
         if (!pcg_takes(a, prob)) continue;   // this launch is not the one that owns the problem (same verdict in every member)
         if (dead) {
@@ -255,76 +301,120 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
             continue;
         }
-        GBDPCG_CL_STAMP(14, 0, ordinal == 1)
-        published = 1;
-        const uint32_t e0 = ordinal * epochs_per_problem;   // epochs e0 + 1 .. e0 + 2 max_iter + 2 belong to this problem
+        GBDPCG_CL_STAMP_RT(14, 0, ordinal == 3)
+        float total = 0.f, g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f, part;
+        uint32_t hidx = 0xffffffffu;
+        bool ok = true;
+        if (!greeted) {
+            // HELLO (epoch 1): where does everybody run?  The payload of every partial granule is the sender's XCD id.
+            greeted = true;
+            const float my_id = __builtin_bit_cast(float, xcc_id);
+            if (tid == 0) bci[0] = 0u;
+            wg_barrier();
+            GBDPCG_CL_HANDOFF(1u, my_id, 0.f, 0.f, xa, total, g0, g1, h0, h1, hidx, ok)
+            if (wave == POLL) {
+                uint32_t lo = lane;
+                asm volatile("" : "+v"(lo));
+                const bool mine = lo >= 4 * H || (fbits(g0) == xcc_id && fbits(g1) == xcc_id);
+                const bool all_here = __all(mine);
+                if (lane == 0) {
+                    bci[0] = ok ? 0u : 2u;
+                    bci[1] = ok && all_here ? 1u : 0u;
+                }
+            }
+            wg_barrier();
+            same_xcd = bci[1] != 0u;
+            if (bci[0] == 2u) {   // the cluster never got together: nothing of it is solved
+                dead = true;
+                if (h == 0 && tid == 0) {
+                    a.iters[prob] = 0xffffffffu;
+                    if (a.max_iter_exit) a.max_iter_exit[prob] = 2;
+                }
+                wg_barrier();
+                continue;
+            }
+        }
+        const uint32_t e0 = 1u + ordinal * epochs_per_problem;   // epochs e0 + 1 .. e0 + 2 max_iter + 2 belong to this problem
         const float *S = a.S + prob * mstride;
         const float *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;   // nullptr: identity preconditioner
         const size_t voff = (size_t)prob * len;
 
         // lambda and gamma of this lane's rows and the two halo knots of lambda (straight from the input vector: no member
-        // writes lambda before every member has passed its first hand-off) are requested BEFORE the tiles, so that their
-        // round trips run under the 300 KB of tile loads instead of in front of the first product
+        // writes lambda before every member has passed its first hand-off) are requested next to the first tile stages, so
+        // that their round trips run under the 300 KB of tile loads instead of in front of the first product
         float lamv[V], gamv[V], halo_lam = 0.f;
+        auto request_vectors = [&]() {
+            uint32_t lo = lane;
+            asm volatile("" : "+v"(lo));   // addresses from the lane number, not from registers held since the kernel started
+            const size_t g0 = voff + (size_t)k_lo * n + wave * (Dg::BPW * n) + 2 * lo;
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            lamv[j] = dc.live ? a.lambda[voff + grow0 + j] : 0.f;
-            gamv[j] = dc.live ? a.gamma[voff + grow0 + j] : 0.f;
-        }
-        if (tid < 2 * n) {   // threads [0, n): the knot before the own ones, [n, 2n): the knot after them
-            const int64_t gi = tid < n ? (int64_t)k_lo * n - n + tid : (int64_t)(k_lo + cnt) * n + (tid - n);
-            if (gi >= 0 && gi < (int64_t)len) halo_lam = a.lambda[voff + gi];
-        }
+            for (int j = 0; j < V; ++j) {
+                lamv[j] = dc.live ? a.lambda[g0 + j] : 0.f;
+                gamv[j] = dc.live ? a.gamma[g0 + j] : 0.f;
+            }
+            const uint32_t t = wave * 64 + lo;
+            if (t < 2 * n) {   // threads [0, n): the knot before the own ones, [n, 2n): the knot after them
+                const int64_t gi = t < n ? (int64_t)k_lo * n - n + t : (int64_t)(k_lo + cnt) * n + (t - n);
+                if (gi >= 0 && gi < (int64_t)len) halo_lam = a.lambda[voff + gi];
+            }
+        };
 
         DenseTile<float, NCT, V> tS, tP;
         if constexpr (STAGED) {
             GBDPCG_CL_STAMP(12, 0, ordinal == 0)
-            // this wave's knots [kw, kw + nk) and, per instruction of a stage, the byte offset of this lane's piece from the
-            // first of them (lanes beyond the last piece re-read piece 0 into slots nobody picks up: every lane of every
-            // instruction is live, so a stage is always exactly 7 loads on the wave's counter)
+            // this wave's knots [kw, kw + nk)
             const uint32_t kw = k_lo + wave * Dg::BPW;
             const uint32_t nk = wave * Dg::BPW < cnt ? (cnt - wave * Dg::BPW < Dg::BPW ? cnt - wave * Dg::BPW : Dg::BPW) : 0u;
             const uint32_t kbase = kw < N ? kw : N - 1;
-            uint32_t rel[7];
-#pragma unroll
-            for (uint32_t i = 0; i < 7; ++i) {
-                const uint32_t q = i * 64 + lane, j = q / kClPieces, piece = q - j * kClPieces;
-                rel[i] = j < nk ? j * (3 * n * n * 4) + piece * 16 : 0u;
-            }
             float *buf0 = reinterpret_cast<float *>(stage_raw) + wave * kClStageFloats;
             float *buf1 = buf0 + Dg::WAVES * kClStageFloats;
             const uint32_t lds0 = (uint32_t)(uintptr_t)buf0, lds1 = (uint32_t)(uintptr_t)buf1;
             const float *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
             const uint32_t b9 = dc.live ? lane / Dg::LPB : 0u;
             // six stages (S: L D R, Pinv: L D R), two in flight, alternating buffers
-            cluster_stage_issue(Sw, rel, lds0);
-            cluster_stage_issue(Sw + n * n, rel, lds1);
+            cluster_stage_issue(Sw, lane, nk, lds0);
+            cluster_stage_issue(Sw + n * n, lane, nk, lds1);
+            request_vectors();   // younger than two stages: the first wait below is stricter than it has to be, never laxer
             cluster_stage_wait<1>();
             cluster_stage_pick<NCT, V, 0>(buf0, dc, b9, N, tS);
-            cluster_stage_issue(Sw + 2 * n * n, rel, lds0);
+            cluster_stage_issue(Sw + 2 * n * n, lane, nk, lds0);
             cluster_stage_wait<1>();
             cluster_stage_pick<NCT, V, 1>(buf1, dc, b9, N, tS);
-            if (P) cluster_stage_issue(Pw, rel, lds1);
+            if (P) cluster_stage_issue(Pw, lane, nk, lds1);
             if (P) cluster_stage_wait<1>(); else cluster_stage_wait<0>();
             cluster_stage_pick<NCT, V, 2>(buf0, dc, b9, N, tS);
             if (P) {
-                cluster_stage_issue(Pw + n * n, rel, lds0);
+                cluster_stage_issue(Pw + n * n, lane, nk, lds0);
                 cluster_stage_wait<1>();
                 cluster_stage_pick<NCT, V, 0>(buf1, dc, b9, N, tP);
-                cluster_stage_issue(Pw + 2 * n * n, rel, lds1);
+                cluster_stage_issue(Pw + 2 * n * n, lane, nk, lds1);
                 cluster_stage_wait<1>();
                 cluster_stage_pick<NCT, V, 1>(buf0, dc, b9, N, tP);
                 cluster_stage_wait<0>();
                 cluster_stage_pick<NCT, V, 2>(buf1, dc, b9, N, tP);
+            } else {   // never read, but defined on every path: else hipcc carries all of tP around the problem loop
+#pragma unroll
+                for (uint32_t cc = 0; cc < Dg::COLS; ++cc) tP.a[cc][0] = tP.a[cc][1] = 0.f;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last picks are in registers before anything else happens
             GBDPCG_CL_STAMP(13, 0, ordinal == 0)
-            GBDPCG_CL_STAMP(15, 0, ordinal == 1)
+            GBDPCG_CL_STAMP_RT(15, 0, ordinal == 3)
         } else {
+            request_vectors();
             dense_load<float, NCT, V>(S, N, dc, tS);
-            if (P) dense_load<float, NCT, V>(P, N, dc, tP);
+            if (P) {
+                dense_load<float, NCT, V>(P, N, dc, tP);
+            } else {
+#pragma unroll
+                for (uint32_t cc = 0; cc < Dg::COLS; ++cc) tP.a[cc][0] = tP.a[cc][1] = 0.f;
+            }
         }
 
+        if (P) {
+#pragma unroll
+            for (uint32_t t = 0; t < GBDPCG_CL_PTAIL; ++t)
+                ptail[t * THREADS + tid] = make_float2(tP.a[Dg::COLS - GBDPCG_CL_PTAIL + t][0], tP.a[Dg::COLS - GBDPCG_CL_PTAIL + t][1]);
+        }
         float rv[V], pv[V], yv[V];
         // windows: lambda on the own knots and the halos, zeros behind them (rows past the own knots, halos at the ends
         // of the problem); every entry has exactly one writer
@@ -340,11 +430,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         for (uint32_t i = (cnt + 2) * n + tid; i < WINF; i += THREADS) xa[i] = xb[i] = 0.f;
         if (tid == 0) bci[0] = 0u;
         wg_barrier();
-        GBDPCG_CL_STAMP(16, 0, ordinal == 1)
+        GBDPCG_CL_STAMP_RT(16, 0, ordinal == 3)
 
-        float total = 0.f, g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f, part;
-        uint32_t hidx = 0xffffffffu;
-        bool ok = true;
         // r = gamma - S lambda                                            (pcg.cuh:118-126); the boundary knots of r travel
         dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tS, xa, dc, yv);
 #pragma unroll
@@ -360,12 +447,12 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         }
         wg_barrier();
         bool failed = bci[0] == 2u;
-        GBDPCG_CL_STAMP(17, 0, ordinal == 1)
+        GBDPCG_CL_STAMP_RT(17, 0, ordinal == 3)
 
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
         float eta = 0.f;
         if (!failed) {
-            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tP, xb, dc, yv);
+            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, GBDPCG_CL_PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -390,7 +477,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             eta = bc[0];
         }
 
-        GBDPCG_CL_STAMP(18, 0, ordinal == 1)
+        GBDPCG_CL_STAMP_RT(18, 0, ordinal == 3)
         uint32_t iter = 0;
         bool max_iter_exit = true;
         for (; !failed && iter < a.max_iter; ++iter) {                    // pcg.cuh:154
@@ -433,7 +520,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             wg_barrier();
             GBDPCG_CL_STAMP(5, POLL, iter == 3 && ordinal == 0)
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tP, xb, dc, yv);
+            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, GBDPCG_CL_PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -474,7 +561,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             GBDPCG_CL_STAMP(7, POLL, iter == 3 && ordinal == 0)
         }
 
-        GBDPCG_CL_STAMP(19, 0, ordinal == 1)
+        GBDPCG_CL_STAMP_RT(19, 0, ordinal == 3)
         // outputs                                                         (pcg.cuh:212,215)
         if (dc.live && !failed) {
 #pragma unroll
@@ -490,33 +577,43 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         }
         dead = failed;
         wg_barrier();   // the windows and bci are reused by the next problem
-        GBDPCG_CL_STAMP(20, 0, ordinal == 1)
+        GBDPCG_CL_STAMP_RT(20, 0, ordinal == 3)
     }
+
+    GBDPCG_CL_STAMP_RT(22, 0, true)
+    // ---- FIN: leave the own slots in a state no later launch can mistake for a publication --------------------------------
+    if (greeted) {
+        const uint32_t rounds = (a.batch - c + clusters - 1) / clusters;   // problems of this cluster: the same in every member
+        const uint32_t fin = 2u + rounds * epochs_per_problem;             // above every epoch of the launch, at least 6
+        float total = 0.f, g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
+        uint32_t hidx = 0xffffffffu;
+        bool ok = true;
+        if (tid == 0) bci[0] = 0u;
+        wg_barrier();
+        if (!dead) {
+            GBDPCG_CL_HANDOFF(fin, 0.f, 0.f, 0.f, xa, total, g0, g1, h0, h1, hidx, ok)
+            if (wave == POLL && !ok && lane == 0) bci[0] = 2u;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's publications have landed before anything is zeroed
+        __syncthreads();
+        const bool clean_both = dead || bci[0] == 2u;   // nobody is left who could be waiting for a word of this workgroup
+        // every member has published FIN, so every member has consumed all older epochs: the slot of the other parity is
+        // free; the FIN slot keeps its tag (its readers may still be looking at it)
+        const cl_u32x4 z = {0u, 0u, 0u, 0u};
+        for (uint32_t par = 0; par < 2; ++par) {
+            if (!clean_both && par == (fin & 1u)) continue;
+            const int off = (int)(par * par_stride + my_slot + tid * 16);
+            if (tid * 16 < kClSlotBytes) {
+                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(z, region, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(z, region, off, 0, kClSc1);
+            }
+        }
+    }
+    GBDPCG_CL_STAMP_WG(1)
 #undef GBDPCG_CL_HANDOFF
 #undef GBDPCG_CL_STAMP
-
-    // ---- leave the slots zeroed for the next launch --------------------------------------------------------------
-    // Every wave drains its stores, the workgroup meets, one thread counts it in; the workgroup whose add comes last
-    // knows that every other one has drained (no store of this launch can land after the clearing) and, if anyone
-    // published, zeroes all slots and the counter.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ uint32_t last_one;
-    __syncthreads();
-    if (tid == 0) {
-        u64 *ctr = reinterpret_cast<u64 *>(ws);
-        const u64 before = __hip_atomic_fetch_add(ctr, 1ull + ((u64)published << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = (uint32_t)before == grid - 1u;
-        last_one = last ? (((before >> 32) + published) != 0 ? 2u : 1u) : 0u;
-    }
-    __syncthreads();
-    if (last_one != 0u) {
-        if (last_one == 2u) {
-            const cl_u32x4 z = {0u, 0u, 0u, 0u};
-            for (uint32_t off = tid * 16; off < 2u * grid * kClSlotBytes; off += THREADS * 16)
-                __builtin_amdgcn_raw_buffer_store_b128(z, region, (int)off, 0, kClSc1);
-        }
-        if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(ws), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+#undef GBDPCG_CL_STAMP_WG
+#undef GBDPCG_CL_STAMP_RT
 }
 
 // n = 14, fp32, general storage, 72 < N <= 288.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
@@ -530,7 +627,8 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
     return H <= kClMaxH ? H : 0;
 }
 
-size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (size_t)2 * dev.num_cus * kClSlotBytes; }
+// ... plus 16 bytes per CU behind the slots: start / end of every workgroup on the real-time clock (diagnostic build only)
+size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (size_t)2 * dev.num_cus * kClSlotBytes + (size_t)dev.num_cus * 16; }
 
 template <typename T>
 bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
@@ -543,7 +641,7 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         if (clusters > a.batch) clusters = a.batch;
         if (clusters == 0) return false;
         const uint32_t rounds = (a.batch + clusters - 1) / clusters;
-        if ((double)rounds * (2.0 * a.max_iter + 4.0) > 4.0e9) return false;   // epochs are 32-bit tags
+        if ((double)rounds * (2.0 * a.max_iter + 4.0) + 8.0 > 4.0e9) return false;   // epochs are 32-bit tags
         const uint32_t C = (a.N + H - 1) / H;
         static const uint32_t spin_limit = [] {   // polls before a hand-off is given up (test hook; ~1 us per poll)
             const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT");

@@ -39,6 +39,18 @@ for rep in range(10):
     if rep >= 2:
         print("   ", [int(r[i] - r[1]) for i in (2, 3, 4, 5, 6, 7)], "   wave 0:", [int(r[i] - r[8]) for i in (9, 10)],
               "   tile loads of wave 0:", int(r[13] - r[12]), "cycles")
-        if B > 128:
-            print("        second problem of block 0, wave 0, cycles from its start: tiles in | windows + barrier | r, hand-off | p, hand-off | "
-                  "iterations done | outputs + barrier:", [int(r[i] - r[14]) for i in (15, 16, 17, 18, 19, 20)])
+        if B > 3 * 128:
+            print("        fourth problem of block 0, wave 0, us from its start (real-time clock): tiles in | windows + barrier | r, hand-off | "
+                  "p, hand-off | iterations done | outputs + barrier:", [round((r[i] - r[14]) / 100.0, 2) for i in (15, 16, 17, 18, 19, 20)],
+                  "  all problems of block 0: %.1f us" % ((r[22] - r[21]) / 100.0))
+
+# every workgroup's start and end on the real-time clock (last solve)
+wg = (ctypes.c_uint64 * 512)()
+assert hip.hipMemcpy(wg, ctypes.c_void_p(fn(s.h) + 256 + 2 * 256 * 384), 4096, 2) == 0
+nb = min(256, 2 * min(B, 128))
+st = [wg[2 * i] for i in range(nb)]
+en = [wg[2 * i + 1] for i in range(nb)]
+t0 = min(st)
+dur = sorted((e - b) / 100.0 for b, e in zip(st, en))
+print("workgroups: starts spread over %.1f us; end - start min / median / max = %.1f / %.1f / %.1f us; last end - first start = %.1f us"
+      % ((max(st) - t0) / 100.0, dur[0], dur[len(dur) // 2], dur[-1], (max(en) - t0) / 100.0))

@@ -4,9 +4,9 @@
 // under round-robin dispatch -- or (b, b + 1) -- neighbouring XCDs.  Each pair plays ping-pong with data-tagged 8-byte
 // granules {epoch, value} (MI355X_MICROARCH.md, Valid forms, R2): the producer stores, the consumer polls with sc1
 // loads (served by L2), answers, and so on for ROUNDS round trips; all pairs play at the same time, as the workgroups of
-// a clustered solve would.  Store flavours: sc1 (write-through: valid for any placement) and plain (the line stays in
-// the XCD's L2: only a same-XCD poller can see it -- the probe counts the pairs whose two XCC ids differ and lets those
-// time out instead of hanging).  Prints per variant: median / max round-trip time over the pairs, pairs on one XCD.
+// a clustered solve would.  Store flavours: sc1 (write-through: valid for any placement), plain and sc0 (the line stays in
+// the XCD's L2: only a same-XCD poller is entitled to see it -- pairs whose partner never sees the word time out after a
+// short bounded spin instead of hanging).  Prints per variant: median / max round-trip time over the pairs, pairs on one XCD.
 //   hipcc -O2 --offload-arch=gfx950 hop_probe.hip -o hop_probe && ./hop_probe
 #include <hip/hip_runtime.h>
 
@@ -36,8 +36,9 @@ struct Result {
     uint32_t bad;    // payload mismatches
 };
 
-template <bool PLAIN_STORE>
-__global__ __launch_bounds__(64) void hop_kernel(u64 *slots, Result *res, uint32_t rounds, uint32_t stride_pairs, uint32_t spin_limit)
+template <int STORE_AUX>
+__global__ __launch_bounds__(64) void hop_kernel(u64 *slots, Result *res, uint32_t rounds, uint32_t stride_pairs, uint32_t spin_limit,
+                                                  uint32_t shift)
 {
     extern __shared__ unsigned char lds_hog[];
     (void)lds_hog;
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(64) void hop_kernel(u64 *slots, Result *res, uint32
     xcc &= 0xf;
     if (lane == 0) res[pair].xcc[member] = xcc;
     // each member owns one 128-byte line; it writes its own, polls the partner's
-    u64 *mine = slots + (size_t)(2 * pair + member) * 16, *theirs = slots + (size_t)(2 * pair + (member ^ 1u)) * 16;
+    // a block's line is the one of block (b + shift): shift != 0 moves every line to a writer on the NEXT XCD, while the
+    // poller of a line can be the block that wrote it (and may still hold it in its L2) in an earlier launch
+    const uint32_t partner = member == 0 ? b + stride_pairs : b - stride_pairs;
+    u64 *mine = slots + (size_t)((b + shift) % gridDim.x) * 16, *theirs = slots + (size_t)((partner + shift) % gridDim.x) * 16;
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 128, 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(theirs, 0, 128, 0x00020000);
     const uint32_t base = (uint32_t)(*mine >> 32);   // epochs continue from what the last launch left
@@ -62,8 +66,7 @@ __global__ __launch_bounds__(64) void hop_kernel(u64 *slots, Result *res, uint32
             const uint32_t epoch = base + r;
             if (member == 0) {   // ping
                 const u32x2 x = {r * 7u, epoch};
-                if (PLAIN_STORE) *reinterpret_cast<volatile u64 *>(mine) = ((u64)epoch << 32) | (r * 7u);
-                else __builtin_amdgcn_raw_buffer_store_b64(x, rm, 0, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b64(x, rm, 0, 0, STORE_AUX);
             }
             // wait for the partner's word of this epoch
             uint32_t spins = 0;
@@ -78,8 +81,7 @@ __global__ __launch_bounds__(64) void hop_kernel(u64 *slots, Result *res, uint32
             }
             if (member == 1 && ok) {   // pong
                 const u32x2 x = {r * 7u + 1u, epoch};
-                if (PLAIN_STORE) *reinterpret_cast<volatile u64 *>(mine) = ((u64)epoch << 32) | (r * 7u + 1u);
-                else __builtin_amdgcn_raw_buffer_store_b64(x, rm, 0, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b64(x, rm, 0, 0, STORE_AUX);
             }
         }
         const u64 t1 = __builtin_amdgcn_s_memrealtime();
@@ -96,16 +98,16 @@ __global__ __launch_bounds__(64) void hop_kernel(u64 *slots, Result *res, uint32
     }
 }
 
-template <bool PLAIN>
-static void run(const char *tag, u64 *slots, Result *res, uint32_t wgs, uint32_t rounds, uint32_t stride_pairs)
+template <int AUX>
+static void run(const char *tag, u64 *slots, Result *res, uint32_t wgs, uint32_t rounds, uint32_t stride_pairs, uint32_t shift = 0)
 {
     const uint32_t pairs = wgs / 2;
     CK(hipMemset(res, 0, sizeof(Result) * pairs));
-    auto kern = hop_kernel<PLAIN>;
+    auto kern = hop_kernel<AUX>;
     const int lds = 100 * 1024;   // one workgroup per CU
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     for (int rep = 0; rep < 3; ++rep) {   // the last repetition is reported
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(64), lds, nullptr, slots, res, rounds, stride_pairs, 1u << 20);
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(64), lds, nullptr, slots, res, rounds, stride_pairs, AUX == 16 ? 1u << 20 : 1u << 14, shift);
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
     }
@@ -143,10 +145,19 @@ int main()
     CK(hipMemset(slots, 0, (size_t)wgs * 128));
     CK(hipMalloc((void **)&res, sizeof(Result) * wgs));
     printf("%u workgroups (one per CU), 200 round trips per pair, all pairs at once; one round trip = two hand-offs\n", wgs);
-    run<false>("sc1 stores, pairs (b, b+8)", slots, res, wgs, 200, 8);
-    run<false>("sc1 stores, pairs (b, b+1)", slots, res, wgs, 200, 1);
-    run<true>("plain stores, pairs (b, b+8)", slots, res, wgs, 200, 8);
-    run<true>("plain stores, pairs (b, b+1)", slots, res, wgs, 200, 1);
-    run<false>("sc1 stores, pairs (b, b+8), again", slots, res, wgs, 200, 8);
+    run<16>("sc1 stores, pairs (b, b+8)", slots, res, wgs, 200, 8);
+    run<16>("sc1 stores, pairs (b, b+1)", slots, res, wgs, 200, 1);
+    run<0>("plain stores (no cache bits), pairs (b, b+8)", slots, res, wgs, 200, 8);
+    run<0>("plain stores (no cache bits), pairs (b, b+1)", slots, res, wgs, 200, 1);
+    run<1>("sc0 stores, pairs (b, b+8)", slots, res, wgs, 200, 8);
+    run<1>("sc0 stores, pairs (b, b+1)", slots, res, wgs, 200, 1);
+    run<16>("sc1 stores, pairs (b, b+8), again", slots, res, wgs, 200, 8);
+    // Does a line that an XCD wrote with plain stores in one launch (it stays in that L2) go stale for that XCD's pollers
+    // when another XCD writes it in a later launch?  plain (b, b+8), then sc1 (b, b+1) with every line moved one block on:
+    // block b+1 now polls the line it wrote itself in the launch before, which block b (the previous XCD) writes now.
+    run<0>("plain stores, pairs (b, b+8), lines in place", slots, res, wgs, 200, 8);
+    run<16>("sc1 stores, pairs (b, b+1), lines moved by one block", slots, res, wgs, 200, 1, 1);
+    run<0>("plain stores, pairs (b, b+8), lines in place", slots, res, wgs, 200, 8);
+    run<16>("sc1 stores, pairs (b, b+8), lines moved by one block", slots, res, wgs, 200, 8, 1);
     return 0;
 }
