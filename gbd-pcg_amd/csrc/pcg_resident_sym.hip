@@ -339,28 +339,6 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     // LDS byte address of the 256-byte dump area of the prefetch loads (symres_touch), shared by all waves
     const uint32_t dump = (uint32_t)(uintptr_t)(ls + align16<float>(len));
 
-    const uint32_t rp = lane & 7u;
-    // Which pair of block-rows a group owns is free; it is chosen so that the four groups that share an LDS pass
-    // (lanes 0-31 / 32-63 of a wave) own pairs j, j+4, j+8, j+12: their rows of a vector then start 48 banks apart
-    // (a pair is 2n = 28 floats) and the 8-byte accesses of 4 x 7 lanes tile the 64 banks instead of colliding two by
-    // two, as consecutive pairs do (bases 0, 28, 56, 20 mod 64: 13 % of an iteration's LDS-array cycles were conflicts).
-    const uint32_t grp = lane >> 3;
-#if GBDPCG_RS_LINEAR_PAIRS
-    const uint32_t k0 = 2 * (wave * G::GROUPS + grp), k1 = k0 + 1;
-#else
-    const uint32_t k0 = 2 * (16 * (wave >> 1) + 4 * (grp & 3u) + 2 * (wave & 1u) + (grp >> 2)), k1 = k0 + 1;
-#endif
-    const bool live0 = rp < n / 2 && k0 < N, live1 = rp < n / 2 && k1 < N;
-    const uint32_t row0 = (live0 ? k0 * n + rp * 2 : 0u), row1 = (live1 ? k1 * n + rp * 2 : 0u);
-    // x operand windows inside a padded mirror (n zeros before x_0 and after x_{N-1}); dead lanes read row 0
-    const uint32_t xo0 = n + (live0 ? k0 : 0u) * n;
-    // the LDS-resident tile (Pinv k1) of this lane: piece i at ltw[64 i], inside the wave's own block of regions
-    float4_alias *ltw = reinterpret_cast<float4_alias *>(smem + wave * G::GROUPS * G::REGION) + lane;
-    const uint32_t zo1 = n + (live1 ? k1 + 1 : 0u) * n + rp * 2;  // where this lane's k1 -> k1+1 products go
-    const uint32_t zo0 = n + (live0 ? k0 : 0u) * n + rp * 2;      // ... and where the ones for its k0 rows arrive
-    // the lane's own operand entries inside a mirror; dead lanes read the zero padding in front of x_0 instead, so
-    // nothing downstream needs a select (v_cndmask with an SGPR mask turned out to be the costliest VALU op here)
-    const uint32_t own0 = live0 ? n + row0 : 0u, own1 = live1 ? n + row1 : 0u;
     const size_t mstride = (size_t)3 * n * n * N;
 
     // zs: only the rows of even block-rows >= 2 are ever written; row 0 (nothing above block-row 0) and the odd
@@ -370,6 +348,32 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 
     for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
         if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
+        // Everything a lane derives from its number is derived again for every problem, from an opaque copy: hoisted out of
+        // the problem loop these dozen values were spilled to scratch (15 VGPRs) and reloaded in the tile-load phase.
+        uint32_t lane_o = tid & 63u;
+        asm volatile("" : "+v"(lane_o));
+        const uint32_t rp = lane_o & 7u;
+        // Which pair of block-rows a group owns is free; it is chosen so that the four groups that share an LDS pass
+        // (lanes 0-31 / 32-63 of a wave) own pairs j, j+4, j+8, j+12: their rows of a vector then start 48 banks apart
+        // (a pair is 2n = 28 floats) and the 8-byte accesses of 4 x 7 lanes tile the 64 banks instead of colliding two by
+        // two, as consecutive pairs do (bases 0, 28, 56, 20 mod 64: 13 % of an iteration's LDS-array cycles were conflicts).
+        const uint32_t grp = lane_o >> 3;
+    #if GBDPCG_RS_LINEAR_PAIRS
+        const uint32_t k0 = 2 * (wave * G::GROUPS + grp), k1 = k0 + 1;
+    #else
+        const uint32_t k0 = 2 * (16 * (wave >> 1) + 4 * (grp & 3u) + 2 * (wave & 1u) + (grp >> 2)), k1 = k0 + 1;
+    #endif
+        const bool live0 = rp < n / 2 && k0 < N, live1 = rp < n / 2 && k1 < N;
+        const uint32_t row0 = (live0 ? k0 * n + rp * 2 : 0u), row1 = (live1 ? k1 * n + rp * 2 : 0u);
+        // x operand windows inside a padded mirror (n zeros before x_0 and after x_{N-1}); dead lanes read row 0
+        const uint32_t xo0 = n + (live0 ? k0 : 0u) * n;
+        // the LDS-resident tile (Pinv k1) of this lane: piece i at ltw[64 i], inside the wave's own block of regions
+        float4_alias *ltw = reinterpret_cast<float4_alias *>(smem + wave * G::GROUPS * G::REGION) + lane_o;
+        const uint32_t zo1 = n + (live1 ? k1 + 1 : 0u) * n + rp * 2;  // where this lane's k1 -> k1+1 products go
+        const uint32_t zo0 = n + (live0 ? k0 : 0u) * n + rp * 2;      // ... and where the ones for its k0 rows arrive
+        // the lane's own operand entries inside a mirror; dead lanes read the zero padding in front of x_0 instead, so
+        // nothing downstream needs a select (v_cndmask with an SGPR mask turned out to be the costliest VALU op here)
+        const uint32_t own0 = live0 ? n + row0 : 0u, own1 = live1 ? n + row1 : 0u;
         const float *S = a.S + prob * mstride;
         const float *P = a.Pinv + prob * mstride;
         const size_t voff = (size_t)prob * len;
