@@ -590,6 +590,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         bool ok = true;
         if (tid == 0) bci[0] = 0u;
         wg_barrier();
+        (void)total; (void)h0; (void)h1;
         if (!dead) {
             GBDPCG_CL_HANDOFF(fin, 0.f, 0.f, 0.f, xa, total, g0, g1, h0, h1, hidx, ok)
             if (wave == POLL && !ok && lane == 0) bci[0] = 2u;
