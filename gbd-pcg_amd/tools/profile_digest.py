@@ -110,7 +110,7 @@ def main():
             lines.append(f"{cfg:6s} {path:10s} fixed25 {t25['ms_median'] * 1e3:9.1f} us  converged {tc['ms_median'] * 1e3:9.1f} us ({tc['iters_mean']:.1f} it)  "
                          f"{per:8.2f} us/iter  {t25['problem_iters_per_s']:.3e} problem-iter/s  {t25['algorithmic_GBps']:7.0f} GB/s algorithmic")
         open(os.path.join(dst, f"{rnd}_configs.txt"), "w").write("\n".join(lines) + "\n")
-    for name in ("counter_fit.txt", "persist_stamps.txt"):
+    for name in ("counter_fit.txt", "persist_stamps.txt", "cluster.txt", "hop_probe.txt"):
         if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
             open(os.path.join(dst, f"{rnd}_{name}"), "w").write(open(os.path.join(src, name)).read())
     if os.path.exists(os.path.join(src, "bw_probe.txt")):

@@ -36,6 +36,18 @@ echo "[9] phase stamps of the persistent kernel (diagnostic build, if present)"
 if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_stamps.so ]; then
   GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_stamps.so python3 $ROOT/gbd-pcg_amd/tools/persist_stamps.py > $OUT/persist_stamps.txt 2>/dev/null || true
 fi
+echo "[10] the cluster kernel (general storage): time per iteration and fixed cost, phase stamps, and what one hand-off costs"
+{
+  python3 $ROOT/gbd-pcg_amd/tools/ab_cluster.py 128 1024 base
+  python3 $ROOT/gbd-pcg_amd/tools/ab_cluster.py 128 128 base
+  python3 $ROOT/gbd-pcg_amd/tools/ab_cluster.py 128 1 base
+  python3 $ROOT/gbd-pcg_amd/tools/ab_cluster.py 256 1 base
+  if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_clstamps.so ]; then
+    echo "--- diagnostic build with stamps (its iterations are slower than the shipped build's: the stamps sit in the loop)"
+    GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_clstamps.so python3 $ROOT/gbd-pcg_amd/tools/cluster_stamps.py 128 1024 | tail -8
+  fi
+} > $OUT/cluster.txt 2>/dev/null || true
+[ -x $ROOT/gbd-pcg_amd/tools/bin/hop_probe ] && $ROOT/gbd-pcg_amd/tools/bin/hop_probe > $OUT/hop_probe.txt 2>/dev/null || true
 # keep what the digest needs, drop the bulky traces
 find $OUT -name "*.db" -delete 2>/dev/null
 du -sh $OUT
