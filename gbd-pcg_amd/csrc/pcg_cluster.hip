@@ -17,14 +17,16 @@
 // (MI355X_MICROARCH.md, Valid forms, R2; the same protocol as pcg_persist.hip).  One such hand-off between two CUs costs
 // 0.44-0.56 us (tools/hop_probe.hip), against 1.4-2 us for the chip-wide all-gather of the persistent path.
 //
-// Epochs start at 1 in every launch and nothing is initialised by a launch of its own (a solve stays ONE kernel node in a
-// hipGraph): a slot is only ever written by the workgroup that owns it.  Before its first problem a cluster says HELLO
-// (epoch 1: every member publishes the id of the XCD it runs on); after its last one it says FIN (an epoch above all the
-// others).  A member that has gathered FIN knows that every member has consumed everything older, zeroes its slots of the
-// OTHER parity and leaves the FIN tag in this one: the first epochs a later launch polls for in a slot are 1 and 2, FIN is
-// at least 6, and by the time a launch asks a slot for epoch e its owner has rewritten it with e - 2.  (The first form
-// -- the workgroup that finishes last zeroes all slots -- wrote lines from one XCD that another XCD had written, which
-// rules out the plain stores below.)
+// Nothing is initialised or cleared by a launch (a solve stays ONE kernel node in a hipGraph) and a slot is only ever
+// written by the workgroup that owns it.  Epochs start at 1 in every launch, and a tag is {launch number, epoch}: the
+// launch number comes from a word of the workspace that the workgroup finishing LAST (an agent-scope counter tells it)
+// increments, so every workgroup of a launch reads the same one, and whatever an earlier launch left in a slot -- or in
+// some L2 -- carries another launch number and is never taken for a publication of this one.  (Two earlier forms: the
+// last finisher zeroing all slots -- it wrote lines from one XCD that another XCD had written, which rules out the
+// plain stores below; then every owner zeroing its own slots behind a closing hand-off -- on one box a launch that
+// followed a launch with another block-to-XCD mapping accepted stale granules, presumably out of an L2 line that had
+// outlived the kernel boundary; with the launch number in the tag such a line is harmless.)
+// Before its first problem a cluster says HELLO (epoch 1: every member publishes the id of the XCD it runs on).
 // When HELLO shows every member of a cluster on the SAME XCD (members sit 8 blocks apart for that, under round-robin
 // dispatch) the cluster publishes with PLAIN stores: the line stays in the XCD's L2, where the partner's sc1 loads find
 // it -- 0.25 us per hand-off instead of 0.44 (tools/hop_probe.hip; across XCDs a plain store is never seen, hence the
@@ -32,7 +34,7 @@
 // A cluster's workgroups must be resident together: the grid never exceeds one workgroup per CU, members of a cluster have
 // neighbouring block indices (in-order dispatch then splits at most one cluster at a time, and that one only until any
 // workgroup exits), and every spin is bounded: a cluster that cannot complete a hand-off reports max_iter_exit = 2,
-// iters = 0xffffffff for its problems and zeroes its own slots.
+// iters = 0xffffffff for its problems.
 #include <cstdlib>
 
 #include "bt_dense.hpp"
@@ -48,7 +50,7 @@ typedef unsigned int cl_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on gfx950: bit 4 = sc1
 
-// Workspace: [256-byte block (stamps of the diagnostic build) | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
+// Workspace: [256-byte block: stamps of the diagnostic build, words 30 / 31 = finish counter / launch number | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
 //   +0    the 8 wave partials (8 granules)
 //   +128  the first own knot of the product vector, for the left neighbour  (n granules, two per 16-byte store)
 //   +256  the last own knot, for the right neighbour
@@ -138,7 +140,7 @@ __device__ __forceinline__ void cluster_stage_pick(const float *buf, const Dense
 
 template <int NCT, int V, bool STAGED>
 __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsigned char *ws, uint32_t H, uint32_t C,
-                                                          uint32_t clusters, uint32_t spin_limit, uint32_t drop_block)
+                                                          uint32_t clusters, uint32_t spin_limit, uint32_t drop_block, bool no_plain, uint32_t epoch_bits)
 {
     using Dg = DenseGeom<float, NCT, V>;
     static_assert(NCT == 14 && V == 2 && Dg::WAVES == 8, "lane roles below are written for 7 lanes x 2 rows per knot");
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     // reload from scratch sat, with its s_waitcnt vmcnt(0), in front of the very stores the neighbour is waiting for.
 #define GBDPCG_CL_HANDOFF(EPOCH, PART, V0, V1, HWIN, TOTAL, G0, G1, H0, H1, HIDX, OK)                               \
     {                                                                                                                \
-        const uint32_t tag = (EPOCH), par_off = (tag & 1u) * par_stride;                                             \
+        const uint32_t tag = nonce | (EPOCH), par_off = ((EPOCH) & 1u) * par_stride;                                 \
         uint32_t lo = lane;                                                                                          \
         asm volatile("" : "+v"(lo));                                                                                 \
         if (blk != drop_block) {                                                                                     \
@@ -281,10 +283,15 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #define GBDPCG_CL_STAMP_RT(IDX, WAVE, COND)
 #endif
 
-    bool greeted = false;     // HELLO done: this workgroup has written slots (and owes a FIN)
+    // this launch's number, in the tag bits above the epoch (epochs of a launch fit epoch_bits: the host checked)
+    const uint32_t nonce = (uint32_t)((__hip_atomic_load(reinterpret_cast<u64 *>(ws) + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull) << epoch_bits);
+    bool greeted = false;     // HELLO done
     bool same_xcd = false;    // every member of the cluster runs on this XCD: publish with plain stores (set by HELLO)
     bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are reported, not solved
-    uint32_t ordinal = 0;     // problems of this cluster so far: the epochs of a problem continue where the last one stopped
+    // problems of this cluster SOLVED BY THIS LAUNCH so far: the epochs of a problem continue where the last one stopped.
+    // Problems another launch owns do not count: the first epochs a launch polls for must be 1 and 2 whatever the batch
+    // holds.
+    uint32_t ordinal = 0;
     const uint32_t epochs_per_problem = 2u * a.max_iter + 4u;
     uint32_t xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 
     GBDPCG_CL_STAMP_RT(21, 0, true)
     GBDPCG_CL_STAMP_WG(0)
-    for (uint32_t prob = c; prob < a.batch; prob += clusters, ++ordinal) {
+    for (uint32_t prob = c; prob < a.batch; prob += clusters) {
         if (!pcg_takes(a, prob)) continue;   // this launch is not the one that owns the problem (same verdict in every member)
         if (dead) {
             if (h == 0 && tid == 0) {
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 }
             }
             wg_barrier();
-            same_xcd = bci[1] != 0u;
+            same_xcd = bci[1] != 0u && !no_plain;
             if (bci[0] == 2u) {   // the cluster never got together: nothing of it is solved
                 dead = true;
                 if (h == 0 && tid == 0) {
@@ -576,38 +583,22 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (max_iter_exit ? 1 : 0);
         }
         dead = failed;
+        ++ordinal;
         wg_barrier();   // the windows and bci are reused by the next problem
         GBDPCG_CL_STAMP_RT(20, 0, ordinal == 3)
     }
 
     GBDPCG_CL_STAMP_RT(22, 0, true)
-    // ---- FIN: leave the own slots in a state no later launch can mistake for a publication --------------------------------
-    if (greeted) {
-        const uint32_t rounds = (a.batch - c + clusters - 1) / clusters;   // problems of this cluster: the same in every member
-        const uint32_t fin = 2u + rounds * epochs_per_problem;             // above every epoch of the launch, at least 6
-        float total = 0.f, g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
-        uint32_t hidx = 0xffffffffu;
-        bool ok = true;
-        if (tid == 0) bci[0] = 0u;
-        wg_barrier();
-        (void)total; (void)h0; (void)h1;
-        if (!dead) {
-            GBDPCG_CL_HANDOFF(fin, 0.f, 0.f, 0.f, xa, total, g0, g1, h0, h1, hidx, ok)
-            if (wave == POLL && !ok && lane == 0) bci[0] = 2u;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's publications have landed before anything is zeroed
-        __syncthreads();
-        const bool clean_both = dead || bci[0] == 2u;   // nobody is left who could be waiting for a word of this workgroup
-        // every member has published FIN, so every member has consumed all older epochs: the slot of the other parity is
-        // free; the FIN slot keeps its tag (its readers may still be looking at it)
-        const cl_u32x4 z = {0u, 0u, 0u, 0u};
-        for (uint32_t par = 0; par < 2; ++par) {
-            if (!clean_both && par == (fin & 1u)) continue;
-            const int off = (int)(par * par_stride + my_slot + tid * 16);
-            if (tid * 16 < kClSlotBytes) {
-                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(z, region, off, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(z, region, off, 0, kClSc1);
-            }
+    // ---- the workgroup that finishes last gives the next launch its number ------------------------------------------------
+    // (every workgroup of this launch has read the number by then; the counter and the number are only ever touched with
+    // agent-scope atomics)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        u64 *ctl = reinterpret_cast<u64 *>(ws);
+        const u64 before = __hip_atomic_fetch_add(ctl + 30, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == grid - 1u) {
+            __hip_atomic_store(ctl + 30, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ctl + 31, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     GBDPCG_CL_STAMP_WG(1)
@@ -642,7 +633,11 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         if (clusters > a.batch) clusters = a.batch;
         if (clusters == 0) return false;
         const uint32_t rounds = (a.batch + clusters - 1) / clusters;
-        if ((double)rounds * (2.0 * a.max_iter + 4.0) + 8.0 > 4.0e9) return false;   // epochs are 32-bit tags
+        // a tag = {launch number, epoch}: the epochs of a launch take the low epoch_bits of its 32 bits
+        const double epochs = 2.0 + (double)rounds * (2.0 * a.max_iter + 4.0);
+        if (epochs >= (double)(1u << 20)) return false;
+        uint32_t epoch_bits = 1;
+        while ((double)(1u << epoch_bits) <= epochs) ++epoch_bits;
         const uint32_t C = (a.N + H - 1) / H;
         static const uint32_t spin_limit = [] {   // polls before a hand-off is given up (test hook; ~1 us per poll)
             const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT");
@@ -662,8 +657,9 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
             *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (*err != hipSuccess) return true;
         }
+        static const bool no_plain = getenv("GBDPCG_CLUSTER_NO_PLAIN") != nullptr;   // tuning runs: always sc1 stores
         hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, a, static_cast<unsigned char *>(a.cluster_ws), H, C,
-                           clusters, spin_limit, drop_block);
+                           clusters, spin_limit, drop_block, no_plain, epoch_bits);
         *err = hipGetLastError();
         return true;
     } else {

@@ -147,9 +147,10 @@ def test_cluster_full_config3_batch(solver, orc):
         assert np.linalg.norm(res) < 2e-3 * np.linalg.norm(d["gamma"][b])
 
 
-def test_cluster_replays_leave_clean_slots(solver, orc):
-    """Every launch starts its epochs at 1 and relies on the previous launch having zeroed the hand-off slots: a graph
-    replayed back to back, other shapes and iteration limits in between -- always the same answer."""
+def test_cluster_replays_need_no_clearing(solver, orc):
+    """Every launch starts its epochs at 1 and nothing is cleared between launches (a tag carries the launch's number, so
+    what an earlier launch left in a slot is never taken for a publication): a graph replayed back to back, other shapes
+    and iteration limits in between -- always the same answer."""
     n, N, B = 14, 128, 200
     d = synth.gen_numpy(n, N, seed=99, batch=B, dtype=np.float32)
     ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=25)
@@ -178,6 +179,26 @@ def test_cluster_replays_leave_clean_slots(solver, orc):
     assert np.array_equal(again["lambda_"], first["lambda_"])
 
 
+def test_cluster_launches_do_not_see_each_other(solver, orc):
+    """Two launches that use the same epochs for different problems: the first solves three problems per cluster, the second
+    only the LAST quarter of a larger batch (the rest is symmetric and goes to the other kernel), after a kernel sequence
+    that may put the workgroups on other XCDs.  (With tags that were bare epochs and slots cleaned by their owners, this
+    sequence once produced answers built from stale granules on one box; a tag now carries the launch's number.)"""
+    n, N, mi = 14, 128, 3
+    B1, B2 = 384, 512        # 3 and 4 rounds of 128 clusters
+    d = synth.gen_numpy(n, N, seed=31, batch=8, dtype=np.float32)
+    idx1, idx2 = np.arange(B1) % 8, np.arange(B2) % 8
+    run(solver, n, N, B1, d["S"][idx1], d["Pinv"][idx1], d["gamma"][idx1], tol=0.0, max_iter=mi)          # all general
+    S2, P2, g2 = d["S"][idx2].copy(), d["Pinv"][idx2].copy(), d["gamma"][idx2]
+    S2[384:] = unsymmetrize(S2[384:], n, N, 128)                                                        # only these are general
+    out = run(solver, n, N, B2, S2, P2, g2, tol=0.0, max_iter=mi, symmetric=2)
+    sub = np.arange(384, 512, 9)
+    ob = orc.pcg_batch(n, N, len(sub), S2[sub], P2[sub], g2[sub], tol=0.0, max_iter=mi)
+    assert (out["iters"] == mi).all() and (out["flag"] == 1).all()
+    for j, b in enumerate(sub):
+        assert relerr(out["lambda_"][b], ob["lambda_"][j]) < 1e-6, b
+
+
 GIVE_UP = r"""
 import numpy as np, torch
 from gbd_pcg_amd import binding, synth
@@ -195,7 +216,7 @@ clusters = 128
 lost = np.arange(B) % clusters == 1          # block 1 is member 0 of cluster 1 (members sit 8 blocks apart)
 assert (it[lost] == 0xffffffff).all() and (fl[lost] == 2).all(), (it[lost], fl[lost])
 assert (it[~lost] < 20).all() and (fl[~lost] == 0).all()
-# the next launch (no dropped workgroup is a property of the process: same hook) still finds clean slots for the others
+# the next launch (the dropped workgroup is a property of the process: same hook) is as good as the first for the others
 lam.zero_()
 it2, fl2 = s.solve(n, N, B, dS, dP, dg, lam, None, None, tol=1e-6, max_iter=25)
 torch.cuda.synchronize()
@@ -206,7 +227,8 @@ print("GIVE-UP-OK")
 
 def test_cluster_gives_up_instead_of_hanging():
     """A workgroup that never publishes (test hook): its cluster reports max_iter_exit = 2 / iters = 0xffffffff for all of
-    its problems after a bounded spin, every other cluster is unaffected, and the slots are clean for the next launch."""
+    its problems after a bounded spin, every other cluster is unaffected, and the next launch is not disturbed by what the
+    broken one left behind."""
     env = dict(os.environ, GBDPCG_CLUSTER_DROP_WG="1", GBDPCG_CLUSTER_SPIN_LIMIT="20000", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", GIVE_UP], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "GIVE-UP-OK" in out.stdout, out.stdout + out.stderr
