@@ -176,10 +176,15 @@ def test_back_to_back_graph_replays_keep_the_symmetric_path(solver):
 
     per_replay(True)
     synced = per_replay(True)
+    lam_synced = lam.clone()
     queued = per_replay(False)
     graph.close()
     assert int(it.min()) == 10 and int(it.max()) == 10
-    assert queued < 1.5 * synced, (queued, synced)
+    # the kernels differ in summation order: had any problem of a queued replay gone to another kernel, its lambda would
+    # differ in the last bits from the synchronised replays' (since round 2 the general path is only 1.4x slower than the
+    # symmetric one, so time alone no longer tells)
+    assert torch.equal(lam, lam_synced)
+    assert queued < 2.0 * synced, (queued, synced)
 
 
 def test_solve_inside_a_caller_owned_capture(solver, orc):
