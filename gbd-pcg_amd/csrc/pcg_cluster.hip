@@ -583,9 +583,9 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (max_iter_exit ? 1 : 0);
         }
         dead = failed;
-        ++ordinal;
         wg_barrier();   // the windows and bci are reused by the next problem
         GBDPCG_CL_STAMP_RT(20, 0, ordinal == 3)
+        ++ordinal;
     }
 
     GBDPCG_CL_STAMP_RT(22, 0, true)

@@ -62,11 +62,17 @@ def main():
         it = torch.zeros(B, dtype=torch.int32, device="cuda")
         fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
         mat = (3 * N - 2) * n * n * es
-        for path, pname in ((binding.PATH_FUSED, "fused"), (binding.PATH_SPLIT, "split"), (binding.PATH_PERSISTENT, "persist"), (binding.PATH_PERSISTENT_1R, "persist1r")):
+        # "general": the fused path with gbdpcg_set_symmetric(0) -- what storage that is not bit-symmetric gets (the cluster
+        # kernel where the shape has it, else the kernel that streams both matrices every iteration)
+        for path, pname in ((binding.PATH_FUSED, "fused"), (binding.PATH_FUSED, "general"), (binding.PATH_SPLIT, "split"),
+                            (binding.PATH_PERSISTENT, "persist"), (binding.PATH_PERSISTENT_1R, "persist1r")):
             solver.set_path(path)
+            solver.set_symmetric(0 if pname == "general" else 2)
             chosen = solver.choose_path(es, n, N, B)
             if chosen != path:
                 continue  # forced path does not fit this shape
+            if pname == "general" and B == 1 and solver.cluster_members(es, n, N) == 0:
+                continue  # single problems without a cluster form: the same kernel as "fused"
             for tol, iters, tag in ((0.0, 5, "fixed5"), (0.0, 25, "fixed25"), (1e-6, 25, "tol1e-6")):
                 graph = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, tol, iters, it, fl)
 
@@ -85,6 +91,7 @@ def main():
                 print(json.dumps(rec), flush=True)
                 graph.close()
         solver.set_path(binding.PATH_AUTO)
+        solver.set_symmetric(2)
         x = torch.randn_like(gamma)
         y = torch.empty_like(gamma)
         k = [0]

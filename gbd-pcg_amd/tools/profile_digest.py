@@ -46,7 +46,11 @@ def main():
     for sub, tag in (("stats", "bench_kernel_stats"), ("stats_configs", "bench_kernel_stats_with_configs")):
         stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if stats:
-            rows = list(csv.reader(open(stats[0])))
+            # bench.py times the streaming general kernel in a child process, which leaves a stats file of its own: the
+            # bench's is the one with the headline kernel in it
+            stats.sort(key=lambda f: -sum(1 for ln in open(f) if "pcg_resident_sym_kernel" in ln or "gbdpcg" in ln))
+            main = [f for f in stats if "pcg_resident_sym_kernel" in open(f).read()]
+            rows = list(csv.reader(open((main or stats)[0])))
             keep = [rows[0]] + [r for r in rows[1:] if "gbdpcg" in r[0]]
             with open(os.path.join(dst, f"{rnd}_{tag}.csv"), "w", newline="") as f:
                 csv.writer(f).writerows(keep)
@@ -93,7 +97,7 @@ def main():
                  "# path is inside).  fixed5 / fixed25 = exit_tol 0 with 5 / 25 iterations, tol1e-6 = converge; us/iter = (fixed25 - fixed5) / 20",
                  "# = the cost of one more real iteration.  C2 = n14 N64 fp32 x1, C3 = n14 N128 fp32 x1024, C4 = n36 N256 fp64 x1,",
                  "# C2x64 / C4x16 = small batches, C5on1 = config 5's 8192 problems on one GPU; persist = one persistent launch,",
-                 "# persist1r = its opt-in single-reduction form.  GB/s algorithmic = SURVEY 8d full-storage bytes / time."]
+                 "# persist1r = its opt-in single-reduction form,\n# general = the fused path with gbdpcg_set_symmetric(0): what storage that is not bit-symmetric gets (cluster kernel where the shape has it).  GB/s algorithmic = SURVEY 8d full-storage bytes / time."]
         recs = [json.loads(ln) for ln in open(cj) if ln.startswith("{")]
         by = collections.OrderedDict()
         for r in recs:
