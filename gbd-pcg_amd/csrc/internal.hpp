@@ -24,6 +24,24 @@ template <typename A> __device__ __forceinline__ bool pcg_takes(const A &a, uint
     return sym == (a.want == 1);
 }
 
+// The same verdicts for up to 64 problems at once: bit j of the result = this launch owns problem first + j * step
+// (j < count <= 64).  Every lane of the calling wave fetches the verdict bytes of one problem, so a workgroup that walks
+// over many problems pays one memory round trip for all of them instead of one per problem; every wave of a workgroup
+// that calls it gets the same mask.  All 64 lanes must be active.
+template <typename A>
+__device__ __forceinline__ unsigned long long pcg_takes_mask(const A &a, uint32_t first, uint32_t step, uint32_t count, uint32_t lane)
+{
+    if (!a.sel) return count >= 64 ? ~0ull : ((1ull << count) - 1ull);
+    bool mine = false;
+    if (lane < count) {
+        const size_t prob = (size_t)first + (size_t)lane * step;
+        bool sym = true;
+        for (uint32_t c = 0; c < a.sel_stride; ++c) sym &= a.sel[prob * a.sel_stride + c] == 1;
+        mine = sym == (a.want == 1);
+    }
+    return __ballot(mine);
+}
+
 template <typename T> struct SpmvArgs {
     const T *M;
     const T *x;

@@ -346,8 +346,16 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     for (uint32_t i = tid; i < padded; i += G::THREADS) zs[i] = 0.f;
     __syncthreads();
 
-    for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
-        if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
+    // which of this workgroup's problems this launch owns, 64 at a time (one memory round trip for all of them)
+    unsigned long long takes = 0;
+    uint32_t takes_from = 0;
+    for (uint32_t prob = blockIdx.x, pi = 0; prob < a.batch; prob += gridDim.x, ++pi) {
+        if (pi == 0 || pi - takes_from >= 64) {
+            const uint32_t left = (a.batch - prob + gridDim.x - 1) / gridDim.x;
+            takes = pcg_takes_mask(a, prob, gridDim.x, left < 64 ? left : 64u, lane);
+            takes_from = pi;
+        }
+        if (!((takes >> (pi - takes_from)) & 1ull)) continue;  // this launch is not the one that owns the problem
         // Everything a lane derives from its number is derived again for every problem, from an opaque copy: hoisted out of
         // the problem loop these dozen values were spilled to scratch (15 VGPRs) and reloaded in the tile-load phase.
         uint32_t lane_o = tid & 63u;
