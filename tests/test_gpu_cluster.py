@@ -147,6 +147,41 @@ def test_cluster_full_config3_batch(solver, orc):
         assert np.linalg.norm(res) < 2e-3 * np.linalg.norm(d["gamma"][b])
 
 
+def test_cluster_config5_batch_on_one_gpu(solver, orc):
+    """BASELINE config 5's 8192 problems (generated on the device with the seeds 1234 + i of SURVEY.md section 8d) in general
+    storage on one GPU: 64 rounds of 128 clusters in one launch.  Every problem converges in 7..12 iterations, the true
+    residual is small, a warm restart exits after one iteration, and 64 problems from both ends and the middle of the
+    batch equal the oracle run on the same device-formed Pinv."""
+    n, N, B = 14, 128, 8192
+    g = synth.gen_torch_seeded(n, N, 0, B, "cuda", torch.float32, seed=1234)
+    S, gamma = g["S"], g["gamma"]
+    del g
+    P = solver.form_pinv(n, N, B, S, binding.PINV_STAIR)
+    lam = torch.zeros_like(gamma)
+    r, p = torch.empty_like(gamma), torch.empty_like(gamma)
+    solver.set_symmetric(0)
+    try:
+        iters, flags = solver.solve(n, N, B, S, P, gamma, lam, r, p, tol=1e-6, max_iter=25)
+        torch.cuda.synchronize()
+        it = iters.cpu().numpy()
+        assert flags.sum().item() == 0 and it.min() >= 7 and it.max() <= 12, (it.min(), it.max())
+        res = gamma - solver.spmv(n, N, B, S, lam)
+        assert (res.norm(dim=1) / gamma.norm(dim=1)).max().item() < 2e-3
+        assert ((r - res).norm(dim=1) / gamma.norm(dim=1)).max().item() < 1e-5
+        idx = np.r_[0:24, 4090:4106, 8168:8192]
+        ob = orc.pcg_batch(n, N, len(idx), S[idx].cpu().numpy(), P[idx].cpu().numpy(), gamma[idx].cpu().numpy(),
+                           tol=1e-6, max_iter=25, nthreads=8)
+        assert np.array_equal(it[idx], ob["iters"].astype(np.int64))
+        lam_h = lam[idx].cpu().numpy()
+        for k in range(len(idx)):
+            assert relerr(lam_h[k], ob["lambda_"][k]) < 1e-6, (idx[k], it[idx[k]])
+        iters2, flags2 = solver.solve(n, N, B, S, P, gamma, lam, r, p, tol=1e-6, max_iter=25)   # warm restart
+        torch.cuda.synchronize()
+        assert int(iters2.max()) == 1 and int(iters2.min()) == 1 and flags2.sum().item() == 0
+    finally:
+        solver.set_symmetric(2)
+
+
 def test_cluster_replays_need_no_clearing(solver, orc):
     """Every launch starts its epochs at 1 and nothing is cleared between launches (a tag carries the launch's number, so
     what an earlier launch left in a slot is never taken for a publication): a graph replayed back to back, other shapes
