@@ -105,6 +105,12 @@ gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n
  * boundary knots twice per iteration); 0 = the shape has no such form (stateSize 14, fp32, 72 < knotPoints <= 288 only)
  * and general storage is streamed every iteration. */
 uint32_t gbdpcg_cluster_members(uint32_t elem_size, uint32_t n, uint32_t N);
+/* The workgroups of one problem wait for each other inside the kernel (bounded spins), so they must get onto the device
+ * together: the launch never has more workgroups than compute units and keeps the members of a problem next to each other
+ * in dispatch order, which is enough as long as other kernels on the device finish within about a second.  A problem whose
+ * workgroups could not meet is reported with d_max_iter_exit = 2 and d_iters = 0xffffffff (lambda untouched); the other
+ * problems of the batch are not affected.  Setting the environment variable GBDPCG_NO_CLUSTER before the first solve of a
+ * process switches the form off (general storage is then streamed every iteration, 3.4x slower at the config-3 shape). */
 
 /* Symmetric storage.  S and Pinv of an MPC Schur system are symmetric block-tridiagonal, i.e. in
  * storage L_{k+1} == R_k^T for every knot (README.md:8; the symmetric-stair preconditioner of
