@@ -90,6 +90,21 @@ def test_cluster_vs_oracle(solver, orc, N, B):
     check(out, ob, d, B)
 
 
+@pytest.mark.parametrize("N,B", [(250, 70), (150, 100), (288, 64), (100, 130)])
+def test_cluster_more_problems_than_clusters(solver, orc, N, B):
+    """Three- and four-member clusters with more problems than one round holds (64 clusters of four sit 8 blocks apart, 85
+    clusters of three next to each other), and a ragged last round of two-member clusters."""
+    n = 14
+    base = 6
+    d = synth.gen_numpy(n, N, seed=900 + N, batch=base, dtype=np.float32)
+    idx = np.arange(B) % base
+    S, Pi = d["S"][idx], d["Pinv"][idx]
+    g = (d["gamma"][idx] * (1.0 + 0.01 * (np.arange(B) // base))[:, None]).astype(np.float32)
+    ob = orc.pcg_batch(n, N, B, S, Pi, g, tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, S, Pi, g)
+    check(out, ob, {"gamma": g}, B)
+
+
 def test_cluster_identity_preconditioner(solver, orc):
     """d_Pinv == NULL: r~ = r (pcg.cuh with an identity preconditioner); more iterations, same rules."""
     n, N, B = 14, 128, 4
