@@ -312,11 +312,14 @@ def run_rank(args, world, rank, local_rank):
 
     for _ in range(args.warmup):
         step()
-    events = new_events(args.steps)
+    # HIP-event pairs around every EV_EVERY-th step only: an event pair costs the stream ~7 us (gbd-pcg_amd/tools/step_overhead.py:
+    # 0.4226 ms per step with a pair around every step, 0.4155 ms with none), and the events are instrumentation, not work
+    EV_EVERY = 5
+    events = new_events((args.steps + EV_EVERY - 1) // EV_EVERY)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step(events[k // EV_EVERY] if k % EV_EVERY == 0 else None)
     fence()
     elapsed = time.perf_counter() - t0
     # RCCL over xGMI: throughput aggregation only (max elapsed, total problem-iterations)
