@@ -316,6 +316,16 @@ __device__ __forceinline__ void symres_touch(const float *M, uint32_t N, uint32_
                  : "=&s"(keep) : "v"(addr), "s"(lds_dump) : "memory");
 }
 
+// One dword LDS-DMA instruction: the active lanes move 4 bytes each from base + off to lds_addr + 4 * lane.  Like the touch
+// above it is invisible to hipcc's counters; the caller waits (s_waitcnt vmcnt(0)) before the barrier that precedes the
+// first read of the destination.
+__device__ __forceinline__ void symres_dma_dword(const float *base, uint32_t off, uint32_t lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(off), "s"(lds_addr) : "memory");
+}
+
 template <int NCT, bool STAGED>
 __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 {
@@ -385,6 +395,18 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         const float *S = a.S + prob * mstride;
         const float *P = a.Pinv + prob * mstride;
         const size_t voff = (size_t)prob * len;
+        // lambda (into its own array and into the operand mirror) and gamma (into the mirror of r, where r = gamma - S lambda
+        // will replace it) are requested FIRST, by LDS-DMA -- no register, no instruction of the tile phase waits for them --
+        // so that their round trips run under the 400 KB of tile loads instead of in front of the first product
+        // (the cluster kernel's lesson: 3.5 us per problem were spent waiting for 21 KB of vectors).
+        for (uint32_t q = wave; q * 64 < len; q += WAVES) {
+            const uint32_t e = q * 64 + lane_o;
+            if (e < len) {
+                symres_dma_dword(a.lambda + voff, e * 4, (uint32_t)(uintptr_t)(ls + q * 64));
+                symres_dma_dword(a.lambda + voff, e * 4, (uint32_t)(uintptr_t)(xa + n + q * 64));
+                symres_dma_dword(a.gamma + voff, e * 4, (uint32_t)(uintptr_t)(xb + n + q * 64));
+            }
+        }
 
         // Resident for the whole solve: three tiles in registers, the fourth in LDS.  Everything else
         // (lambda, r, p) lives in LDS between the phases; only y crosses a barrier in registers.
@@ -438,15 +460,11 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 #pragma unroll
         for (uint32_t i = 0; i < G::P0_LDS_QUADS; ++i) lt0[i * G::THREADS] = p0.q[i];
 
-        for (uint32_t i = tid; i < len; i += G::THREADS) {
-            const float l = a.lambda[voff + i];
-            ls[i] = l;
-            xa[n + i] = l;
-        }
         for (uint32_t i = tid; i < n; i += G::THREADS) {
             xa[i] = 0.f; xa[n + len + i] = 0.f; xa[2 * n + len + i] = 0.f;
             xb[i] = 0.f; xb[n + len + i] = 0.f; xb[2 * n + len + i] = 0.f;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of lambda and gamma has landed in LDS
         __syncthreads();
 
         // One matrix-vector product over this lane's two block-rows.  XM: padded mirror of the operand.
@@ -489,8 +507,14 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         GBDPCG_SYMRES_PRODUCT(s0, 0, s1, false, xa, part)
         __syncthreads();
         GBDPCG_SYMRES_FINISH_Y()
-        if (live0) *xb0 = make_float2(a.gamma[voff + row0] - y[0][0], a.gamma[voff + row0 + 1] - y[0][1]);
-        if (live1) *xb1 = make_float2(a.gamma[voff + row1] - y[1][0], a.gamma[voff + row1 + 1] - y[1][1]);
+        if (live0) {   // gamma is waiting in the mirror of r
+            const float2 gm = *xb0;
+            *xb0 = make_float2(gm.x - y[0][0], gm.y - y[0][1]);
+        }
+        if (live1) {
+            const float2 gm = *xb1;
+            *xb1 = make_float2(gm.x - y[1][0], gm.y - y[1][1]);
+        }
         __syncthreads();
 
         // Workgroup sum of PART (same order in every thread: the exit branch stays uniform) and the
