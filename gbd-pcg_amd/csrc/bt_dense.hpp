@@ -149,4 +149,120 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
     }
 }
 
+// Staged tile loads.  A wave's knots are contiguous in memory; one block (L, D or R: n^2 floats = 49 pieces of 16 bytes)
+// of each of its up to 9 knots is fetched per stage with 7 LDS-DMA instructions (64 lanes x 16 bytes, dense and
+// coalesced, no VGPR in between) into the wave's own staging buffer, and the lanes then pick their two rows up with
+// 8-byte LDS reads.  The direct form (bt_dense.hpp, dense_load) reads 8 bytes per lane at a 56-byte stride: 84 sparse
+// instructions per matrix, bound by the address path -- in pcg_cluster.hip 28 us of a 40 us round went there.
+constexpr uint32_t kDenseStageChunks = 7 * 64, kDenseStageBytes = kDenseStageChunks * 16, kDenseStageFloats = kDenseStageBytes / 4;
+constexpr uint32_t kDensePieces = 49;   // 16-byte pieces per n x n block, n = 14
+
+// Issue one stage: lane l of instruction i moves the 16-byte piece q = 64 i + l of the wave's `nk` blocks (49 pieces each, blocks
+// 3 n^2 floats apart) from base to lds_addr + 16 q.  Lanes beyond the last piece re-read piece 0 into slots nobody picks
+// up: every lane of every instruction is live, so a stage is always exactly 7 loads on the wave's counter.  The offsets
+// are recomputed from the lane number at every issue (kept in registers across the stages they were spilled, and every
+// reload from scratch came with an s_waitcnt vmcnt(0) that drained the stages in flight).  The loads are written in asm
+// (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with dense_stage_wait before
+// it reads the buffer, and never has more than two stages in flight.
+__device__ __forceinline__ void dense_stage_issue(const float *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
+{
+    uint32_t lo = lane;
+    asm volatile("" : "+v"(lo));
+    uint32_t rel[7];
+#pragma unroll
+    for (uint32_t i = 0; i < 7; ++i) {
+        const uint32_t q = i * 64 + lo, j = (q * 1338u) >> 16;   // q / 49 for q < 448
+        rel[i] = j < nk ? q * 16 + j * (3 * 14 * 14 * 4 - kDensePieces * 16) : 0u;
+    }
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "s"(lds_addr)
+                 : "memory", "scc");
+}
+// all but the youngest `newer` stages (7 loads each) of this wave have landed
+template <int NEWER> __device__ __forceinline__ void dense_stage_wait()
+{
+    if constexpr (NEWER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+}
+
+typedef float2 __attribute__((may_alias)) dense_float2_alias;
+
+// This lane's two rows of block BLK (0 = L, 1 = D, 2 = R) out of the wave's staging buffer into its tile.
+template <int NCT, int V, int BLK>
+__device__ __forceinline__ void dense_stage_pick(const float *buf, const DenseCtx<float, NCT, V> &dc, uint32_t b9, uint32_t N,
+                                                   DenseTile<float, NCT, V> &tl)
+{
+    constexpr uint32_t n = NCT;
+    // L_0 and R_{N-1} are never used (pcg.cuh:105-106); lanes without a row hold zeros
+    const bool keep = dc.live && !(BLK == 0 && dc.k == 0) && !(BLK == 2 && dc.k == N - 1);
+    const dense_float2_alias *src = reinterpret_cast<const dense_float2_alias *>(buf + b9 * n * n + dc.rp * 2);
+#pragma unroll
+    for (uint32_t c = 0; c < n; ++c) {
+        const float2 v = src[c * n / 2];
+        tl.a[BLK * n + c][0] = keep ? v.x : 0.f;
+        tl.a[BLK * n + c][1] = keep ? v.y : 0.f;
+    }
+}
+
+
+template <int NCT, int V> constexpr size_t dense_stage_lds_bytes() { return (size_t)2 * DenseGeom<float, NCT, V>::WAVES * kDenseStageBytes; }
+
+// Both tiles of a workgroup's knots [k_lo, k_lo + cnt) through the staging buffers (`stage`: dense_stage_lds_bytes of LDS, 16-byte
+// aligned; matrices 16-byte aligned): six stages (S: L D R, Pinv: L D R; three when P == nullptr), two in flight, alternating
+// buffers.  `between` is called once, behind the first two stage issues: loads requested there (vectors) are younger than
+// two stages, which makes the first wait stricter than it has to be, never laxer.  tP is defined on every path (zeros
+// without a preconditioner): a conditionally loaded tile is carried around the caller's problem loop by hipcc, all of it.
+template <int NCT, int V, typename Between>
+__device__ __forceinline__ void dense_staged_load(const float *S, const float *P, uint32_t N, const DenseCtx<float, NCT, V> &dc,
+                                                  uint32_t wave, uint32_t lane, uint32_t k_lo, uint32_t cnt, float *stage,
+                                                  DenseTile<float, NCT, V> &tS, DenseTile<float, NCT, V> &tP, Between between)
+{
+    using Dg = DenseGeom<float, NCT, V>;
+    constexpr uint32_t n = NCT;
+    // this wave's knots [kw, kw + nk)
+    const uint32_t kw = k_lo + wave * Dg::BPW;
+    const uint32_t nk = wave * Dg::BPW < cnt ? (cnt - wave * Dg::BPW < Dg::BPW ? cnt - wave * Dg::BPW : Dg::BPW) : 0u;
+    const uint32_t kbase = kw < N ? kw : N - 1;
+    float *buf0 = stage + wave * kDenseStageFloats;
+    float *buf1 = buf0 + Dg::WAVES * kDenseStageFloats;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)buf0, lds1 = (uint32_t)(uintptr_t)buf1;
+    const float *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
+    const uint32_t b9 = dc.live ? lane / Dg::LPB : 0u;
+    dense_stage_issue(Sw, lane, nk, lds0);
+    dense_stage_issue(Sw + n * n, lane, nk, lds1);
+    between();
+    dense_stage_wait<1>();
+    dense_stage_pick<NCT, V, 0>(buf0, dc, b9, N, tS);
+    dense_stage_issue(Sw + 2 * n * n, lane, nk, lds0);
+    dense_stage_wait<1>();
+    dense_stage_pick<NCT, V, 1>(buf1, dc, b9, N, tS);
+    if (P) dense_stage_issue(Pw, lane, nk, lds1);
+    if (P) dense_stage_wait<1>(); else dense_stage_wait<0>();
+    dense_stage_pick<NCT, V, 2>(buf0, dc, b9, N, tS);
+    if (P) {
+        dense_stage_issue(Pw + n * n, lane, nk, lds0);
+        dense_stage_wait<1>();
+        dense_stage_pick<NCT, V, 0>(buf1, dc, b9, N, tP);
+        dense_stage_issue(Pw + 2 * n * n, lane, nk, lds1);
+        dense_stage_wait<1>();
+        dense_stage_pick<NCT, V, 1>(buf0, dc, b9, N, tP);
+        dense_stage_wait<0>();
+        dense_stage_pick<NCT, V, 2>(buf1, dc, b9, N, tP);
+    } else {
+#pragma unroll
+        for (uint32_t cc = 0; cc < Dg::COLS; ++cc) tP.a[cc][0] = tP.a[cc][1] = 0.f;
+    }
+}
+
 }  // namespace gbdpcg

@@ -70,72 +70,6 @@ constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
 #define GBDPCG_CL_CHAINS 3   // accumulator chains of a block-row product (bt_dense.hpp, dense_mv); 1 for A/B builds
 #endif
 
-// Staged tile loads.  A wave's knots are contiguous in memory; one block (L, D or R: n^2 floats = 49 pieces of 16 bytes)
-// of each of its up to 9 knots is fetched per stage with 7 LDS-DMA instructions (64 lanes x 16 bytes, dense and
-// coalesced, no VGPR in between) into the wave's own staging buffer, and the lanes then pick their two rows up with
-// 8-byte LDS reads.  The direct form (bt_dense.hpp, dense_load) reads 8 bytes per lane at a 56-byte stride: 84 sparse
-// instructions per matrix, bound by the address path -- 28 us of a 40 us round went there.
-constexpr uint32_t kClStageChunks = 7 * 64, kClStageBytes = kClStageChunks * 16, kClStageFloats = kClStageBytes / 4;
-constexpr uint32_t kClPieces = 49;   // 16-byte pieces per n x n block, n = 14
-
-// Issue one stage: lane l of instruction i moves the 16-byte piece q = 64 i + l of the wave's `nk` blocks (49 pieces each, blocks
-// 3 n^2 floats apart) from base to lds_addr + 16 q.  Lanes beyond the last piece re-read piece 0 into slots nobody picks
-// up: every lane of every instruction is live, so a stage is always exactly 7 loads on the wave's counter.  The offsets
-// are recomputed from the lane number at every issue (kept in registers across the stages they were spilled, and every
-// reload from scratch came with an s_waitcnt vmcnt(0) that drained the stages in flight).  The loads are written in asm
-// (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with cluster_stage_wait before
-// it reads the buffer, and never has more than two stages in flight.
-__device__ __forceinline__ void cluster_stage_issue(const float *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
-{
-    uint32_t lo = lane;
-    asm volatile("" : "+v"(lo));
-    uint32_t rel[7];
-#pragma unroll
-    for (uint32_t i = 0; i < 7; ++i) {
-        const uint32_t q = i * 64 + lo, j = (q * 1338u) >> 16;   // q / 49 for q < 448
-        rel[i] = j < nk ? q * 16 + j * (3 * 14 * 14 * 4 - kClPieces * 16) : 0u;
-    }
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
-                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "s"(lds_addr)
-                 : "memory", "scc");
-}
-// all but the youngest `newer` stages (7 loads each) of this wave have landed
-template <int NEWER> __device__ __forceinline__ void cluster_stage_wait()
-{
-    if constexpr (NEWER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-}
-
-typedef float2 __attribute__((may_alias)) cl_float2_alias;
-
-// This lane's two rows of block BLK (0 = L, 1 = D, 2 = R) out of the wave's staging buffer into its tile.
-template <int NCT, int V, int BLK>
-__device__ __forceinline__ void cluster_stage_pick(const float *buf, const DenseCtx<float, NCT, V> &dc, uint32_t b9, uint32_t N,
-                                                   DenseTile<float, NCT, V> &tl)
-{
-    constexpr uint32_t n = NCT;
-    // L_0 and R_{N-1} are never used (pcg.cuh:105-106); lanes without a row hold zeros
-    const bool keep = dc.live && !(BLK == 0 && dc.k == 0) && !(BLK == 2 && dc.k == N - 1);
-    const cl_float2_alias *src = reinterpret_cast<const cl_float2_alias *>(buf + b9 * n * n + dc.rp * 2);
-#pragma unroll
-    for (uint32_t c = 0; c < n; ++c) {
-        const float2 v = src[c * n / 2];
-        tl.a[BLK * n + c][0] = keep ? v.x : 0.f;
-        tl.a[BLK * n + c][1] = keep ? v.y : 0.f;
-    }
-}
-
 }  // namespace
 
 template <int NCT, int V, bool STAGED>
@@ -151,7 +85,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out
     // the last GBDPCG_CL_PTAIL columns of this lane's block-row of Pinv (two rows each): see dense_mv, TAIL
     __shared__ __attribute__((aligned(16))) float2 ptail[(GBDPCG_CL_PTAIL ? GBDPCG_CL_PTAIL : 1) * THREADS];
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: [2][8 waves][kClStageBytes]
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: dense_stage_lds_bytes (bt_dense.hpp)
 
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -378,40 +312,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         DenseTile<float, NCT, V> tS, tP;
         if constexpr (STAGED) {
             GBDPCG_CL_STAMP(12, 0, ordinal == 0)
-            // this wave's knots [kw, kw + nk)
-            const uint32_t kw = k_lo + wave * Dg::BPW;
-            const uint32_t nk = wave * Dg::BPW < cnt ? (cnt - wave * Dg::BPW < Dg::BPW ? cnt - wave * Dg::BPW : Dg::BPW) : 0u;
-            const uint32_t kbase = kw < N ? kw : N - 1;
-            float *buf0 = reinterpret_cast<float *>(stage_raw) + wave * kClStageFloats;
-            float *buf1 = buf0 + Dg::WAVES * kClStageFloats;
-            const uint32_t lds0 = (uint32_t)(uintptr_t)buf0, lds1 = (uint32_t)(uintptr_t)buf1;
-            const float *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
-            const uint32_t b9 = dc.live ? lane / Dg::LPB : 0u;
-            // six stages (S: L D R, Pinv: L D R), two in flight, alternating buffers
-            cluster_stage_issue(Sw, lane, nk, lds0);
-            cluster_stage_issue(Sw + n * n, lane, nk, lds1);
-            request_vectors();   // younger than two stages: the first wait below is stricter than it has to be, never laxer
-            cluster_stage_wait<1>();
-            cluster_stage_pick<NCT, V, 0>(buf0, dc, b9, N, tS);
-            cluster_stage_issue(Sw + 2 * n * n, lane, nk, lds0);
-            cluster_stage_wait<1>();
-            cluster_stage_pick<NCT, V, 1>(buf1, dc, b9, N, tS);
-            if (P) cluster_stage_issue(Pw, lane, nk, lds1);
-            if (P) cluster_stage_wait<1>(); else cluster_stage_wait<0>();
-            cluster_stage_pick<NCT, V, 2>(buf0, dc, b9, N, tS);
-            if (P) {
-                cluster_stage_issue(Pw + n * n, lane, nk, lds0);
-                cluster_stage_wait<1>();
-                cluster_stage_pick<NCT, V, 0>(buf1, dc, b9, N, tP);
-                cluster_stage_issue(Pw + 2 * n * n, lane, nk, lds1);
-                cluster_stage_wait<1>();
-                cluster_stage_pick<NCT, V, 1>(buf0, dc, b9, N, tP);
-                cluster_stage_wait<0>();
-                cluster_stage_pick<NCT, V, 2>(buf1, dc, b9, N, tP);
-            } else {   // never read, but defined on every path: else hipcc carries all of tP around the problem loop
-#pragma unroll
-                for (uint32_t cc = 0; cc < Dg::COLS; ++cc) tP.a[cc][0] = tP.a[cc][1] = 0.f;
-            }
+            dense_staged_load<NCT, V>(S, P, N, dc, wave, lane, k_lo, cnt, reinterpret_cast<float *>(stage_raw), tS, tP,
+                                      request_vectors);   // the vectors are requested behind the first two tile stages
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last picks are in registers before anything else happens
             GBDPCG_CL_STAMP(13, 0, ordinal == 0)
             GBDPCG_CL_STAMP_RT(15, 0, ordinal == 3)
@@ -660,7 +562,7 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
         const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
         auto kern = staged ? pcg_cluster_kernel<14, 2, true> : pcg_cluster_kernel<14, 2, false>;
-        const size_t lds = staged ? (size_t)2 * DenseGeom<float, 14, 2>::WAVES * kClStageBytes : 0;
+        const size_t lds = staged ? dense_stage_lds_bytes<14, 2>() : 0;
         // on every launch, like the other launchers: HIP keeps the attribute per device
         if (lds) {
             *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -26,7 +26,9 @@ __device__ __forceinline__ T wg_sum_r(T part, T *red, uint32_t lane, uint32_t wa
     return tot;
 }
 
-template <typename T, int NCT, int V>
+// STAGED (fp32, n = 14, matrices 16-byte aligned): the tiles come in through LDS-DMA staging buffers -- dense, coalesced
+// 16-byte pieces instead of 8 bytes per lane at a 56-byte stride (bt_dense.hpp, dense_staged_load).
+template <typename T, int NCT, int V, bool STAGED = false>
 __global__ __launch_bounds__(512) void pcg_resident_kernel(PcgArgs<T> a)
 {
     using Dg = DenseGeom<T, NCT, V>;
@@ -42,6 +44,8 @@ __global__ __launch_bounds__(512) void pcg_resident_kernel(PcgArgs<T> a)
     const uint32_t padded = align16<T>((N + 2) * n);
     T *xa = smem, *xb = xa + padded;          // padded mirrors of p (lambda in the prologue) and r
     T *red0 = xb + padded, *red1 = red0 + WAVES;
+    const uint32_t stage_offset_floats = align16<float>(2 * padded + 2 * align16<T>(WAVES));   // STAGED only (T = float)
+    (void)stage_offset_floats;
     const DenseCtx<T, NCT, V> dc(wave, lane, N);
     const uint32_t row0 = (dc.live ? dc.kl : 0u) * n + dc.rp * V;  // first of this lane's rows
     const size_t mstride = (size_t)3 * n * n * N;
@@ -52,8 +56,15 @@ __global__ __launch_bounds__(512) void pcg_resident_kernel(PcgArgs<T> a)
         const size_t voff = (size_t)prob * len;
 
         DenseTile<T, NCT, V> tS, tP;
-        dense_load<T, NCT, V>(S, N, dc, tS);
-        if (P) dense_load<T, NCT, V>(P, N, dc, tP);
+        if constexpr (STAGED) {
+            // the staging buffers sit behind the mirrors and the reduction words in dynamic LDS (16-byte aligned)
+            float *stage = reinterpret_cast<float *>(smem_raw) + stage_offset_floats;
+            dense_staged_load<NCT, V>(S, P, N, dc, wave, lane, 0u, N, stage, tS, tP, [] {});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            dense_load<T, NCT, V>(S, N, dc, tS);
+            if (P) dense_load<T, NCT, V>(P, N, dc, tP);
+        }
 
         T lamv[V], rv[V], pv[V], yv[V];
 #pragma unroll
@@ -174,9 +185,22 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
     static_assert(2 * Dg::REGS <= 176, "resident matrices must leave registers for the solve");
     const uintptr_t al = RV * sizeof(T);
     if ((reinterpret_cast<uintptr_t>(a.S) % al) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % al)) return false;
-    const size_t lds = ((size_t)2 * align16<T>((a.N + 2) * a.n) + 2 * align16<T>(Dg::WAVES)) * sizeof(T);
+    size_t lds = ((size_t)2 * align16<T>((a.N + 2) * a.n) + 2 * align16<T>(Dg::WAVES)) * sizeof(T);
     uint32_t grid = (uint32_t)dev.num_cus;  // one resident workgroup owns a CU's register file
     if (grid > a.batch) grid = a.batch;
+    if constexpr (sizeof(T) == 4) {
+        static const bool no_staging = getenv("GBDPCG_RES_DIRECT_LOADS") != nullptr;   // tuning runs only
+        const bool staged = !no_staging && !(reinterpret_cast<uintptr_t>(a.S) % 16) && !(a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 16);
+        if (staged) {
+            lds = (lds + 15) / 16 * 16 + dense_stage_lds_bytes<14, RV>();
+            auto kern = pcg_resident_kernel<T, 14, RV, true>;
+            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (*err != hipSuccess) return true;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(Dg::WAVES * 64), lds, s, a);
+            *err = hipGetLastError();
+            return true;
+        }
+    }
     hipLaunchKernelGGL((pcg_resident_kernel<T, 14, RV>), dim3(grid), dim3(Dg::WAVES * 64), lds, s, a);
     *err = hipGetLastError();
     return true;
