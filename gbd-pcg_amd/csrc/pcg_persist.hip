@@ -300,7 +300,7 @@ template <typename T, int NCT> struct PersistGeom {
 
 template <typename T, int NCT, int K, bool HAS_PINV>
 __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_kernel(PcgArgs<T> a, u64 *ws_all, uint32_t W,
-                                                                                     uint32_t spin_limit)
+                                                                                     uint32_t spin_limit, uint32_t staged)
 {
     using Gm = PersistGeom<T, NCT>;
     constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
@@ -357,13 +357,51 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
         const T *Pk = (HAS_PINV ? P : S) + (size_t)(knot_live ? k : 0u) * 3 * n * n;
         // all 2 * COLS loads first (one memory round trip), the selections afterwards
         T sraw[COLS], praw[COLS];
+        if (staged) {
+            // The block-rows of the workgroup's K knots are contiguous in memory: LDS-DMA brings them in as dense 16-byte
+            // pieces (the direct form below reads 8 bytes per lane at a stride of n elements) and the lanes pick their
+            // elements up from LDS.  Knots past the end of the problem re-read the last one (masked below).
+            extern __shared__ __attribute__((aligned(16))) unsigned char persist_stage[];
+            constexpr uint32_t PPK = 3 * n * n * sizeof(T) / 16;   // 16-byte pieces per knot
+            static_assert((3 * n * n * sizeof(T)) % 16 == 0, "whole pieces per knot");
+            T *stS = reinterpret_cast<T *>(persist_stage), *stP = stS + K * 3 * n * n;
+            uint32_t lo = lane;
+            asm volatile("" : "+v"(lo));
+            for (uint32_t q0 = wave * 64; q0 < K * PPK; q0 += THREADS) {
+                const uint32_t q = q0 + lo;
+                if (q < K * PPK) {
+                    const uint32_t j = q / PPK, piece = q - j * PPK, kk = k0 + j < N ? k0 + j : N - 1;
+                    const uint32_t off = (kk - (k0 < N ? k0 : N - 1)) * (3 * n * n * (uint32_t)sizeof(T)) + piece * 16;
+                    const T *Sb = S + (size_t)(k0 < N ? k0 : N - 1) * 3 * n * n;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "s"(Sb), "v"(off), "s"((uint32_t)(uintptr_t)stS + q0 * 16) : "memory");
+                    if (HAS_PINV) {
+                        const T *Pb = P + (size_t)(k0 < N ? k0 : N - 1) * 3 * n * n;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "s"(Pb), "v"(off), "s"((uint32_t)(uintptr_t)stP + q0 * 16) : "memory");
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
 #pragma unroll
-        for (uint32_t i = 0; i < COLS; ++i) {
-            const uint32_t c = cbase + i;
-            const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
-            const uint32_t idx = valid ? c * n + row : n * n;   // else an element of D_k: always there
-            sraw[i] = Sk[idx];
-            if (HAS_PINV) praw[i] = Pk[idx];
+            for (uint32_t i = 0; i < COLS; ++i) {
+                const uint32_t c = cbase + i;
+                const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
+                const uint32_t idx = slot * 3 * n * n + (valid ? c * n + row : n * n);
+                sraw[i] = stS[idx];
+                if (HAS_PINV) praw[i] = stP[idx];
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < COLS; ++i) {
+                const uint32_t c = cbase + i;
+                const bool valid = row_live && knot_live && c < 3 * n && !(k == 0 && c < n) && !(k == N - 1 && c >= 2 * n);
+                const uint32_t idx = valid ? c * n + row : n * n;   // else an element of D_k: always there
+                sraw[i] = Sk[idx];
+                if (HAS_PINV) praw[i] = Pk[idx];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -848,8 +886,19 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
             return hipErrorInvalidValue;
         }
     } else {
-        if (a.Pinv) hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
-        else hipLaunchKernelGGL((pcg_persist_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
+        // staged matrix loads (LDS-DMA) when both block-row sets of a workgroup fit the dynamic LDS next to the windows
+        // and the matrices are 16-byte aligned
+        static const bool no_staging = getenv("GBDPCG_PERSIST_DIRECT_LOADS") != nullptr;   // tuning runs only
+        const size_t stage = (size_t)(a.Pinv ? 2 : 1) * K * 3 * NCT * NCT * sizeof(T);
+        const bool staged = !no_staging && stage <= 128 * 1024 && !(reinterpret_cast<uintptr_t>(a.S) % 16) &&
+                            !(a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 16);
+        const size_t lds = staged ? stage : 0;
+        auto kern = a.Pinv ? pcg_persist_kernel<T, NCT, K, true> : pcg_persist_kernel<T, NCT, K, false>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, ws, W, spin_limit, staged ? 1u : 0u);
     }
     return hipGetLastError();
 }
