@@ -3,13 +3,14 @@
 gbdpcg_set_symmetric(0): the cluster kernel alone; then a mixed batch in the default mode: check kernel, resident symmetric
 kernel, cluster kernel for the last quarter) and compare every general-storage problem of the mixed launches with the CPU
 oracle (the checker).  On one box the sequence once produced answers built from stale hand-off granules; tags carry the
-launch number since.     python gbd-pcg_amd/tools/cluster_mixed_stress.py [repeats=40]"""
+launch number since.  Lives under tests/ because it uses the oracle (test infrastructure) as the checker.
+     python tests/stress/cluster_mixed_stress.py [repeats=40]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/stress/ -> repo root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gbd_pcg_amd import binding, synth  # noqa: E402
