@@ -105,6 +105,16 @@ def test_cluster_more_problems_than_clusters(solver, orc, N, B):
     check(out, ob, {"gamma": g}, B)
 
 
+def test_cluster_declines_what_its_tags_cannot_count(solver, orc):
+    """A tag is {launch number, epoch} in 32 bits and a launch may use at most 2^20 epochs: with max_iter = 200000 the
+    launch is not eligible and the streaming kernel solves the problems instead -- same answers."""
+    n, N, B = 14, 128, 3
+    d = synth.gen_numpy(n, N, seed=12, batch=B, dtype=np.float32)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=200000)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], max_iter=200000)
+    check(out, ob, d, B)
+
+
 def test_cluster_identity_preconditioner(solver, orc):
     """d_Pinv == NULL: r~ = r (pcg.cuh with an identity preconditioner); more iterations, same rules."""
     n, N, B = 14, 128, 4
