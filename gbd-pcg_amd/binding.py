@@ -31,6 +31,7 @@ SYMBOLS = [
     "gbdpcg_graph_launch", "gbdpcg_graph_destroy", "gbdpcg_form_pinv_f32", "gbdpcg_form_pinv_f64",
     "gbdpcg_form_pinv_solve_f32", "gbdpcg_form_pinv_solve_f64",
     "gbdpcg_graph_create_form_pinv_solve_f32", "gbdpcg_graph_create_form_pinv_solve_f64",
+    "gbdpcg_form_schur_f32", "gbdpcg_form_schur_f64", "gbdpcg_recover_primal_f32", "gbdpcg_recover_primal_f64",
     "gbdpcg_csr_to_bt_f32", "gbdpcg_csr_to_bt_f64", "gbdpcg_version",
 ]
 
@@ -250,6 +251,32 @@ class Solver:
         self._check(fn(self.h, ctypes.c_uint32(n), ctypes.c_uint32(N), ctypes.c_uint32(batch), _p(S),
                        _p(Pinv), ctypes.c_int(kind), self._stream(stream)), "form_pinv")
         return Pinv
+
+    def form_schur(self, nx, nu, N, batch, G, C, g, c, S=None, gamma=None, Ginv=None, want_ginv=True, stream=None):
+        """gbdpcg_form_schur_*: packed KKT blocks (layouts in include/gbdpcg.h) -> S, gamma and (optionally) G^-1."""
+        import torch
+        suf, _ = _suffix(G)
+        if S is None:
+            S = torch.empty(batch * 3 * nx * nx * N, dtype=G.dtype, device=G.device)
+        if gamma is None:
+            gamma = torch.empty(batch * nx * N, dtype=G.dtype, device=G.device)
+        if Ginv is None and want_ginv:
+            Ginv = torch.empty_like(G)
+        fn = getattr(self.lib, f"gbdpcg_form_schur_{suf}")
+        self._check(fn(self.h, ctypes.c_uint32(nx), ctypes.c_uint32(nu), ctypes.c_uint32(N), ctypes.c_uint32(batch), _p(G),
+                       _p(C), _p(g), _p(c), _p(S), _p(gamma), _p(Ginv), self._stream(stream)), "form_schur")
+        return S, gamma, Ginv
+
+    def recover_primal(self, nx, nu, N, batch, Ginv, C, g, lam, z=None, stream=None):
+        """gbdpcg_recover_primal_*: z = -G^-1 (g + C' lambda), the layout of g."""
+        import torch
+        suf, _ = _suffix(Ginv)
+        if z is None:
+            z = torch.empty_like(g)
+        fn = getattr(self.lib, f"gbdpcg_recover_primal_{suf}")
+        self._check(fn(self.h, ctypes.c_uint32(nx), ctypes.c_uint32(nu), ctypes.c_uint32(N), ctypes.c_uint32(batch), _p(Ginv),
+                       _p(C), _p(g), _p(lam), _p(z), self._stream(stream)), "recover_primal")
+        return z
 
 
 class Graph:

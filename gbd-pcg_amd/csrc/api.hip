@@ -526,6 +526,31 @@ gbdpcg_status csr_to_bt_impl(uint32_t n, uint32_t N, const uint32_t *row_ptr, co
 
 }  // namespace
 
+namespace {
+template <typename T>
+gbdpcg_status form_schur_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *d_G, const T *d_C,
+                              const T *d_g, const T *d_c, T *d_S, T *d_gamma, T *d_Ginv, void *stream)
+{
+    if (!h || !d_G || !d_g || !d_c || !d_S || !d_gamma || (!d_C && N > 1) || nu == 0 || !shape_ok(nx, N, batch))
+        return GBDPCG_ERR_INVALID;
+    if (!schur_shape_ok<T>(h->dev, nx, nu)) return GBDPCG_ERR_UNSUPPORTED;
+    DEVICE_SCOPE(h);
+    HIP_TRY(h, launch_form_schur<T>(h->dev, nx, nu, N, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, (hipStream_t)stream));
+    return GBDPCG_OK;
+}
+template <typename T>
+gbdpcg_status recover_primal_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *d_Ginv,
+                                  const T *d_C, const T *d_g, const T *d_lambda, T *d_z, void *stream)
+{
+    if (!h || !d_Ginv || !d_g || !d_lambda || !d_z || (!d_C && N > 1) || nu == 0 || !shape_ok(nx, N, batch))
+        return GBDPCG_ERR_INVALID;
+    if (!schur_shape_ok<T>(h->dev, nx, nu)) return GBDPCG_ERR_UNSUPPORTED;
+    DEVICE_SCOPE(h);
+    HIP_TRY(h, launch_recover_primal<T>(h->dev, nx, nu, N, batch, d_Ginv, d_C, d_g, d_lambda, d_z, (hipStream_t)stream));
+    return GBDPCG_OK;
+}
+}  // namespace
+
 extern "C" {
 
 gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
@@ -822,6 +847,31 @@ gbdpcg_status gbdpcg_form_pinv_f64(gbdpcg_handle_t h, uint32_t n, uint32_t N, ui
     DEVICE_SCOPE(h);
     HIP_TRY(h, launch_form_pinv<double>(h->dev, n, N, batch, d_S, d_Pinv, (int)kind, (hipStream_t)stream));
     return GBDPCG_OK;
+}
+
+gbdpcg_status gbdpcg_form_schur_f32(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const float *d_G,
+                                    const float *d_C, const float *d_g, const float *d_c, float *d_S, float *d_gamma,
+                                    float *d_Ginv, void *stream)
+{
+    return form_schur_impl<float>(h, nx, nu, N, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, stream);
+}
+gbdpcg_status gbdpcg_form_schur_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const double *d_G,
+                                    const double *d_C, const double *d_g, const double *d_c, double *d_S, double *d_gamma,
+                                    double *d_Ginv, void *stream)
+{
+    return form_schur_impl<double>(h, nx, nu, N, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, stream);
+}
+gbdpcg_status gbdpcg_recover_primal_f32(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                        const float *d_Ginv, const float *d_C, const float *d_g, const float *d_lambda,
+                                        float *d_z, void *stream)
+{
+    return recover_primal_impl<float>(h, nx, nu, N, batch, d_Ginv, d_C, d_g, d_lambda, d_z, stream);
+}
+gbdpcg_status gbdpcg_recover_primal_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                        const double *d_Ginv, const double *d_C, const double *d_g, const double *d_lambda,
+                                        double *d_z, void *stream)
+{
+    return recover_primal_impl<double>(h, nx, nu, N, batch, d_Ginv, d_C, d_g, d_lambda, d_z, stream);
 }
 
 gbdpcg_status gbdpcg_form_pinv_solve_f32(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const float *d_S,

@@ -164,4 +164,13 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
                             T *Pinv, int kind, hipStream_t s, uint8_t *verdicts = nullptr);
 template <typename T> uint32_t pinv_verdict_chunks(uint32_t n, uint32_t N, int kind);
 
+// ---- schur.hip: KKT blocks -> S, gamma, G^-1;  lambda -> primal step.  Layouts in include/gbdpcg.h.
+template <typename T>
+hipError_t launch_form_schur(const DeviceInfo &dev, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *G, const T *C,
+                             const T *g, const T *c, T *S, T *gamma, T *Ginv, hipStream_t s);
+template <typename T>
+hipError_t launch_recover_primal(const DeviceInfo &dev, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *Ginv,
+                                 const T *C, const T *g, const T *lambda, T *z, hipStream_t s);
+template <typename T> bool schur_shape_ok(const DeviceInfo &dev, uint32_t nx, uint32_t nu);
+
 }  // namespace gbdpcg

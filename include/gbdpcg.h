@@ -280,6 +280,39 @@ gbdpcg_status gbdpcg_graph_create_form_pinv_solve_f64(gbdpcg_handle_t h, uint32_
                                                       double tol, uint32_t max_iter, uint32_t *d_iters,
                                                       uint8_t *d_max_iter_exit, gbdpcg_graph_t *out);
 
+/* The MPCGPU steps either side of the solve (f4): forming S and gamma from the KKT blocks of a batch of linearised
+ * MPC problems, and recovering the primal step from lambda.  The reference tree has no code for them (README.md:2-11
+ * states the system that comes out, README.md:66-77 cites the paper), so the convention is fixed here:
+ *
+ *     minimise    sum_k  1/2 x_k' Q_k x_k + q_k' x_k  +  sum_{k<N-1} 1/2 u_k' R_k u_k + r_k' u_k
+ *     subject to  x_0 = c_0,    x_{k+1} - A_k x_k - B_k u_k = c_{k+1}                       (k = 0 .. knotPoints-1)
+ *
+ * i.e. 1/2 z'Gz + g'z subject to Cz = c, z = (x_0, u_0, x_1, ..., x_{N-1}); Gz + g + C'lambda = 0 gives
+ *     S lambda = gamma,  S = C G^-1 C',  gamma = -(c + C G^-1 g),      z = -G^-1 (g + C' lambda)
+ * with D_0 = Q_0^-1, D_k = A_j Q_j^-1 A_j' + B_j R_j^-1 B_j' + Q_k^-1 (j = k-1), L_k = -A_j Q_j^-1, R_k = L_{k+1}'.
+ * Packed device arrays, one problem after the other, every block column-major (nx = stateSize, nu = controlSize):
+ *     d_G    [Q_0 R_0 Q_1 R_1 ... Q_{N-1}]   (nx^2+nu^2) N - nu^2     cost Hessians, symmetric positive definite
+ *     d_C    [A_0 B_0 A_1 B_1 ... B_{N-2}]   (nx^2+nx nu)(N-1)        dynamics Jacobians (A: nx x nx, B: nx x nu)
+ *     d_g    [q_0 r_0 q_1 r_1 ... q_{N-1}]   (nx+nu) N - nu           cost gradients; d_z has this layout too
+ *     d_c    [c_0 ... c_{N-1}]               nx N                     constraint residuals
+ *     d_S, d_gamma                            3 nx^2 N, nx N           what gbdpcg_solve_* takes (n = nx)
+ *     d_Ginv                                  as d_G                   every block inverted (may be NULL in form_schur)
+ * The S written is exactly symmetric in storage (L_{k+1} == R_k' bit for bit), so the default symmetric mode of the solve
+ * takes its resident kernels.  Shapes whose per-row working set exceeds one compute unit's LDS (7 nx^2 + 3 nu^2 elements
+ * > 160 KB) give GBDPCG_ERR_UNSUPPORTED. */
+gbdpcg_status gbdpcg_form_schur_f32(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                    const float *d_G, const float *d_C, const float *d_g, const float *d_c,
+                                    float *d_S, float *d_gamma, float *d_Ginv, void *stream);
+gbdpcg_status gbdpcg_form_schur_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                    const double *d_G, const double *d_C, const double *d_g, const double *d_c,
+                                    double *d_S, double *d_gamma, double *d_Ginv, void *stream);
+gbdpcg_status gbdpcg_recover_primal_f32(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                        const float *d_Ginv, const float *d_C, const float *d_g,
+                                        const float *d_lambda, float *d_z, void *stream);
+gbdpcg_status gbdpcg_recover_primal_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                        const double *d_Ginv, const double *d_C, const double *d_g,
+                                        const double *d_lambda, double *d_z, void *stream);
+
 /* CSR ingestion (f3): repacks a host CSR matrix (csr_t<T>, include/types.cuh:7-15) whose
  * sparsity lies inside the block-tridiagonal pattern into the [L|D|R] layout (host arrays).
  * Entries outside the pattern give GBDPCG_ERR_INVALID.  Implements what the stub overload

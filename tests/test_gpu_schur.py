@@ -1,0 +1,129 @@
+"""SURVEY 8f-4 on the device (csrc/schur.hip, through the C ABI): KKT blocks -> S, gamma, G^-1 and lambda -> primal step,
+against oracle/schur_oracle.py (fp64 block formulas, themselves pinned to a dense KKT solve in test_oracle_schur.py).
+PARITY UNPINNED: the reference tree has no code, fixture or output for these steps.  Tolerances: the device inverts the
+cost blocks by Gauss-Jordan in working precision, so entries agree with the fp64 formulas to cond(Q) * eps -- 2e-4 of the
+largest entry in fp32 (cost blocks of condition <= 30 here), 1e-11 in fp64."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from gbd_pcg_amd import binding  # noqa: E402
+from oracle import schur_oracle as so  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    s = binding.Solver(0)
+    yield s
+    s.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-300)
+
+
+SHAPES = [(14, 7, 128, 3), (14, 7, 1, 2), (14, 7, 2, 1), (2, 1, 5, 4), (3, 3, 2, 1), (5, 2, 9, 2), (12, 4, 33, 2), (4, 6, 3, 2),
+          (36, 18, 6, 1), (1, 1, 4, 1), (44, 3, 3, 1)]
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-4), (np.float64, 1e-11)])
+@pytest.mark.parametrize("nx,nu,N,B", SHAPES)
+def test_form_schur_and_recover_vs_oracle(solver, nx, nu, N, B, dtype, tol):
+    d = so.gen(nx, nu, N, seed=100 + nx + N, batch=B, dtype=dtype)
+    dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
+    S, gamma, Ginv = solver.form_schur(nx, nu, N, B, dG, dC, dg, dc)
+    torch.cuda.synchronize()
+    S, gamma, Ginv = S.cpu().numpy().reshape(B, -1), gamma.cpu().numpy().reshape(B, -1), Ginv.cpu().numpy().reshape(B, -1)
+    rng = np.random.default_rng(1)
+    lam = rng.standard_normal((B, nx * N)).astype(dtype)
+    z = solver.recover_primal(nx, nu, N, B, dev(Ginv.reshape(-1)), dC, dg, dev(lam.reshape(-1)))
+    torch.cuda.synchronize()
+    z = z.cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        oS, og, oGi = so.form_schur(nx, nu, N, d["G"][b], d["C"][b], d["g"][b], d["c"][b])
+        assert close(S[b], oS, tol), "S"
+        assert close(gamma[b], og, tol), "gamma"
+        assert close(Ginv[b], oGi, tol), "Ginv"
+        assert close(z[b], so.recover_primal(nx, nu, N, d["G"][b], d["C"][b], d["g"][b], lam[b]), 10 * tol), "z"
+        # storage symmetry, bit for bit: L_{k+1} == R_k', corner blocks zero
+        Sb = S[b].reshape(N, 3, nx, nx)
+        assert not Sb[0, 0].any() and not Sb[N - 1, 2].any()
+        for k in range(N - 1):
+            assert np.array_equal(Sb[k + 1, 0], Sb[k, 2].T)
+
+
+def test_form_schur_blocks_wider_than_a_wavefront(solver):
+    """nx = 66 > 64 lanes: every per-row loop of the kernels takes a second trip (fp32 only: the fp64 working set of this
+    block size exceeds one compute unit's LDS and is refused)."""
+    test_form_schur_and_recover_vs_oracle(solver, 66, 2, 3, 1, np.float32, 2e-4)
+
+
+def test_form_schur_without_ginv_and_bad_arguments(solver):
+    nx, nu, N, B = 14, 7, 8, 2
+    d = so.gen(nx, nu, N, seed=3, batch=B, dtype=np.float32)
+    dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
+    S1, g1, _ = solver.form_schur(nx, nu, N, B, dG, dC, dg, dc)
+    S2, g2, none = solver.form_schur(nx, nu, N, B, dG, dC, dg, dc, want_ginv=False)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(S1, S2) and torch.equal(g1, g2)
+    lib = solver.lib
+    import ctypes
+    u = ctypes.c_uint32
+    assert lib.gbdpcg_form_schur_f32(solver.h, u(nx), u(0), u(N), u(B), *(ctypes.c_void_p(t.data_ptr()) for t in (dG, dC, dg, dc, S1, g1)),
+                                     None, None) == 1
+    assert lib.gbdpcg_form_schur_f32(solver.h, u(nx), u(nu), u(N), u(B), None, *(ctypes.c_void_p(t.data_ptr()) for t in (dC, dg, dc, S1, g1)),
+                                     None, None) == 1
+    # a block size whose working set does not fit one compute unit's LDS
+    assert lib.gbdpcg_form_schur_f64(solver.h, u(80), u(40), u(N), u(1), *(ctypes.c_void_p(t.data_ptr()) for t in (dG, dC, dg, dc, S1, g1)),
+                                     None, None) == 4
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 3e-4), (np.float64, 1e-9)])
+def test_kkt_to_primal_step_end_to_end(solver, dtype, tol):
+    """What one SQP iteration of MPCGPU does around the solve, all on the device: KKT blocks -> S, gamma -> stair Pinv ->
+    PCG -> primal step; the step and the multipliers against numpy.linalg.solve of the whole KKT system (fp64).  The formed S
+    passes the bit-for-bit symmetry test, so the default mode runs its symmetric kernels on it."""
+    nx, nu, N, B = 14, 7, 64, 6
+    d = so.gen(nx, nu, N, seed=21, batch=B, dtype=dtype)
+    dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
+    S, gamma, Ginv = solver.form_schur(nx, nu, N, B, dG, dC, dg, dc)
+    assert bool(solver.check_symmetric(nx, N, B, S).all())
+    Pinv = torch.empty_like(S)
+    lam = torch.zeros_like(gamma)
+    it, fl = solver.form_pinv_solve(nx, N, B, S, Pinv, gamma, lam, kind=binding.PINV_STAIR,
+                                    tol=1e-10 if dtype == np.float32 else 1e-22, max_iter=200)
+    z = solver.recover_primal(nx, nu, N, B, Ginv, dC, dg, lam)
+    torch.cuda.synchronize()
+    assert not fl.cpu().numpy().any() and (it.cpu().numpy() < 200).all()
+    z, lam = z.cpu().numpy().reshape(B, -1), lam.cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        oz, ol = so.dense_kkt_solve(nx, nu, N, d["G"][b], d["C"][b], d["g"][b], d["c"][b])
+        assert np.linalg.norm(lam[b] - ol) <= tol * np.linalg.norm(ol)
+        assert np.linalg.norm(z[b] - oz) <= tol * np.linalg.norm(oz)
+
+
+def test_form_schur_full_config3_batch(solver):
+    """The BASELINE batch shape (1024 problems, stateSize 14, knotPoints 128): size-independent checks on every problem
+    (storage symmetry via the device test) and the oracle on a sample."""
+    nx, nu, N, B = 14, 7, 128, 1024
+    base = so.gen(nx, nu, N, seed=77, batch=8, dtype=np.float32)
+    reps = B // 8
+    arr = {k: np.tile(base[k], (reps, 1)) for k in "GCgc"}
+    arr["g"] = arr["g"] * (1.0 + np.arange(B, dtype=np.float32)[:, None] / B)   # gamma differs from problem to problem
+    dG, dC, dg, dc = (dev(arr[k].reshape(-1)) for k in "GCgc")
+    S, gamma, Ginv = solver.form_schur(nx, nu, N, B, dG, dC, dg, dc)
+    assert bool(solver.check_symmetric(nx, N, B, S).all())
+    Sh, gh = S.cpu().numpy().reshape(B, -1), gamma.cpu().numpy().reshape(B, -1)
+    for b in (0, 9, 515, 1023):
+        assert np.array_equal(Sh[b], Sh[b % 8])   # S depends on G and C only
+        oS, og, _ = so.form_schur(nx, nu, N, arr["G"][b], arr["C"][b], arr["g"][b], arr["c"][b])
+        assert close(Sh[b], oS, 2e-4) and close(gh[b], og, 2e-4)
