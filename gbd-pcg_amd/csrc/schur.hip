@@ -23,6 +23,8 @@
 // LDS operations of one wave execute in program order, so the synchronisation inside a wave is a compiler fence
 // (group_sync<64> of pinv.hip restated).  A row's working set is 7 nx^2 + 3 nu^2 + ... elements of LDS (7.5 KB at
 // nx = 14, nu = 7, fp32): four waves per workgroup while they fit 64 KB, one otherwise.
+#include <cstdlib>
+
 #include "bt_device.hpp"
 #include "internal.hpp"
 
@@ -203,6 +205,258 @@ __global__ __launch_bounds__(256) void schur_form_kernel(uint32_t nx, uint32_t n
     }
 }
 
+// ---- compile-time block sizes NX, NU <= 15 and knotPoints a multiple of 4: FOUR knots per wavefront, registers instead of LDS ----
+// The kernel above pays two LDS reads per fma and a pair of wave syncs per pivot step of a tableau it walks with runtime
+// indices: 1.44 ms for the 131072 rows of the BASELINE batch (1024 x 128, nx 14, nu 7), 0.5 TB/s.  Here a wavefront WALKS along
+// a run of consecutive knots of one problem, four at a time, one knot per 16-lane quarter:
+//   * lane l < NX of a quarter owns column l of Q_j (then of Q_j^-1, W_j = A_j Q_j^-1, T_j = W_j A_j' + V_j B_j'), lane l < NU
+//     column l of R_j (R_j^-1, V_j = B_j R_j^-1) in registers with static indices; the spare lane NX carries q_j as one more column
+//     through the elimination and the product (-> Q_j^-1 q_j, A_j Q_j^-1 q_j), lane NU carries r_j: the vectors cost nothing;
+//   * the elimination is the in-place Gauss-Jordan of pinv_diag_quad_kernel (pinv.hip), Q and R steps interleaved so that both
+//     share one LDS round trip per step (the pivot column is broadcast through a 16-element LDS line per quarter);
+//   * operands a whole quarter needs (columns of A_j, B_j, W_j, V_j) are broadcast reads of LDS;
+//   * every Q_j is inverted ONCE: T_j, W_j and the vector A e_j + B f_j of knot j stay in LDS slots for the quarter (or, across a
+//     step, the carry slot) that builds row j+1 from them.  A run that does not start at knot 0 first runs one step on the four
+//     knots before it with the stores switched off.  With one run per problem (batch >= 1024) nothing is computed twice;
+//   * the inputs of the NEXT step (4 x 574 elements: G, C, g, c of four knots are contiguous) arrive by dword LDS-DMA while this
+//     step computes -- no registers, no instructions beyond the 38 requests -- and all outputs leave as dense 256-byte stores
+//     gathered from LDS (S rows [L_j | D_j | R_j] with L_j = -W_{j-1}, R_j = -W_j' read transposed; G^-1 in place of G).
+// R_j and L_{j+1} are copies of the same registers, so S is exactly symmetric in storage as above.  Not bit-identical with
+// the general kernel (no mirroring of the inverses, other summation order): both are held to the fp64 formulas by the tests.
+namespace {
+
+__device__ __forceinline__ void dma_dword(const void *base, uint32_t byte_off, uint32_t lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(byte_off), "s"(lds_addr) : "memory");
+}
+
+template <typename T, int NX, int NU> struct QuadGeom {
+    static constexpr uint32_t CP = 16;  // padded column
+    static constexpr uint32_t SG = NX * NX + NU * NU, SC = NX * NX + NX * NU, SV = NX + NU;
+    // raw inputs of one step (four knots), as they lie in memory
+    static constexpr uint32_t RG = 0, RC = RG + 4 * SG, Rg = RC + 4 * SC, Rc = Rg + 4 * SV, RAW = Rc + 4 * NX;
+    static constexpr uint32_t RAW_P = (RAW + 3) & ~3u;
+    static constexpr uint32_t WSL = 2 * RAW_P;                    // 5 slots of (NX+1) padded columns: -[W_j | A e_j]
+    static constexpr uint32_t TSL = WSL + 5 * (NX + 1) * CP;      // 5 slots of NX padded columns: T_j
+    static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of (NU+1) padded columns: [V_j | B f_j]
+    static constexpr uint32_t DSL = VSL + 5 * (NU + 1) * CP;      // 4 x NX*NX: D_j, unpadded column-major
+    static constexpr uint32_t BCQ = DSL + 4 * NX * NX, BCR = BCQ + 4 * CP, GAM = BCR + 4 * CP;
+    static constexpr uint32_t TOTAL = (GAM + 4 * NX + 3) & ~3u;
+    static constexpr uint32_t SROW = 3 * NX * NX;
+    static constexpr uint32_t OUT_T = (4 * SROW + 63) / 64;       // trips of the S write-out
+};
+
+}  // namespace
+
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_t run, uint32_t waves, const T *__restrict__ G,
+                                                            const T *__restrict__ C, const T *__restrict__ g,
+                                                            const T *__restrict__ c, T *__restrict__ S, T *__restrict__ gamma,
+                                                            T *__restrict__ Ginv)
+{
+    using Q = QuadGeom<T, NX, NU>;
+    static_assert(NX <= 15 && NU <= 15 && NU <= NX, "one knot per 16-lane quarter, one spare lane for the vector");
+    constexpr uint32_t CP = Q::CP, DW = sizeof(T) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *lds = reinterpret_cast<T *>(smem_raw);
+    uint32_t lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const uint32_t l = lane & 15u, qd = lane >> 4;
+    const uint32_t w = blockIdx.x;
+    if (w >= waves) return;
+    const uint32_t rpp = N / run;                 // runs per problem
+    const uint32_t prob = w / rpp, j_start = (w - prob * rpp) * run;
+    const KktDims d(NX, NU, N);
+    const T *Gp = G + (size_t)prob * d.szG, *Cp = C + (size_t)prob * d.szC, *gp = g + (size_t)prob * d.szg, *cp = c + (size_t)prob * d.szc;
+
+    // where the elements this lane stores in the S write-out sit in LDS (the same every step)
+    uint32_t src[Q::OUT_T];
+#pragma unroll
+    for (uint32_t t = 0; t < Q::OUT_T; ++t) {
+        const uint32_t e = t * 64 + lane;
+        const uint32_t q = e / Q::SROW, i = e - q * Q::SROW, slot = i / (NX * NX), ii = i - slot * (NX * NX), cc = ii / NX, r = ii - cc * NX;
+        src[t] = slot == 0 ? Q::WSL + q * (NX + 1) * CP + cc * CP + r
+                 : slot == 1 ? Q::DSL + q * NX * NX + ii
+                             : Q::WSL + (q + 1) * (NX + 1) * CP + r * CP + cc;
+    }
+    // carry slots of a run that starts a problem: L_0 = 0, D_0 = Q_0^-1, gamma_0 = -(c_0 + Q_0^-1 q_0)
+    for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + i] = T(0);
+    for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + i] = T(0);
+    for (uint32_t i = lane; i < (NU + 1) * CP; i += 64) lds[Q::VSL + i] = T(0);
+
+    // requests for the four knots from jb on into raw buffer b (elements past the end of the problem's arrays are not requested)
+    auto request = [&](uint32_t jb, uint32_t b) {
+        const uint32_t base = (uint32_t)(uintptr_t)(lds + b * Q::RAW_P);
+        const uint32_t lim_G = (uint32_t)(d.szG - (size_t)jb * Q::SG) * DW, lim_C = jb < N - 1 ? (uint32_t)(d.szC - (size_t)jb * Q::SC) * DW : 0u;
+        const uint32_t lim_g = (uint32_t)(d.szg - (size_t)jb * Q::SV) * DW;
+        const T *sG = Gp + (size_t)jb * Q::SG, *sC = Cp + (size_t)jb * Q::SC, *sg = gp + (size_t)jb * Q::SV, *sc = cp + (size_t)jb * NX;
+#pragma unroll
+        for (uint32_t o = 0; o < 4 * Q::SG * DW; o += 64)
+            if (o + lane < 4 * Q::SG * DW && o + lane < lim_G) dma_dword(sG, (o + lane) * 4, base + (Q::RG * DW + o) * 4);
+#pragma unroll
+        for (uint32_t o = 0; o < 4 * Q::SC * DW; o += 64)
+            if (o + lane < 4 * Q::SC * DW && o + lane < lim_C) dma_dword(sC, (o + lane) * 4, base + (Q::RC * DW + o) * 4);
+#pragma unroll
+        for (uint32_t o = 0; o < 4 * Q::SV * DW; o += 64)
+            if (o + lane < 4 * Q::SV * DW && o + lane < lim_g) dma_dword(sg, (o + lane) * 4, base + (Q::Rg * DW + o) * 4);
+#pragma unroll
+        for (uint32_t o = 0; o < 4 * NX * DW; o += 64)
+            if (o + lane < 4 * NX * DW) dma_dword(sc, (o + lane) * 4, base + (Q::Rc * DW + o) * 4);
+    };
+
+    const bool pre = j_start != 0;                     // one silent step on the four knots before the run
+    const uint32_t j_first = pre ? j_start - 4 : j_start, j_end = j_start + run;
+    request(j_first, 0);
+    uint32_t b = 0;
+    for (uint32_t jb = j_first; jb < j_end; jb += 4, b ^= 1u) {
+        const bool emit = jb >= j_start;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (jb + 4 < j_end) request(jb + 4, b ^ 1u);
+        T *raw = lds + b * Q::RAW_P;
+        T *rQ = raw + Q::RG + qd * Q::SG, *rR = rQ + NX * NX, *rA = raw + Q::RC + qd * Q::SC, *rB = rA + NX * NX;
+        if (jb + 4 == N) {  // the last knot has no R, A, B, r in memory: R = I, the rest 0 (W = V = 0: R_{N-1} = 0)
+            T *lR = raw + Q::RG + 3 * Q::SG + NX * NX, *lA = raw + Q::RC + 3 * Q::SC, *lr = raw + Q::Rg + 3 * Q::SV + NX;
+            for (uint32_t i = lane; i < NU * NU; i += 64) lR[i] = (i / NU == i % NU) ? T(1) : T(0);
+            for (uint32_t i = lane; i < Q::SC; i += 64) lA[i] = T(0);
+            if (lane < NU) lr[lane] = T(0);
+        }
+        wave_sync();
+        // this lane's columns: Q_j (lane NX: q_j), R_j (lane NU: r_j)
+        T Qc[NX], Rc[NU];
+#pragma unroll
+        for (uint32_t r = 0; r < NX; ++r) Qc[r] = l < NX ? rQ[l * NX + r] : (l == NX ? raw[Q::Rg + qd * Q::SV + r] : T(0));
+#pragma unroll
+        for (uint32_t r = 0; r < NU; ++r) Rc[r] = l < NU ? rR[l * NU + r] : (l == NU ? raw[Q::Rg + qd * Q::SV + NX + r] : T(0));
+        T *bq = lds + Q::BCQ + qd * CP, *br = lds + Q::BCR + qd * CP;
+#pragma unroll
+        for (uint32_t j = 0; j < NX; ++j) {
+            if (l == j) {
+#pragma unroll
+                for (uint32_t r = 0; r < NX; ++r) bq[r] = Qc[r];
+                if (j < NU) {
+#pragma unroll
+                    for (uint32_t r = 0; r < NU; ++r) br[r] = Rc[r];
+                }
+            }
+            wave_sync();
+            T cj[NX], cr[NU];
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) cj[r] = bq[r];
+            if (j < NU) {
+#pragma unroll
+                for (uint32_t r = 0; r < NU; ++r) cr[r] = br[r];
+            }
+            wave_sync();  // everyone has the columns before step j+1 overwrites them
+            const bool is_j = l == j;
+            {
+                const T piv = T(1) / cj[j];
+                const T pr = is_j ? piv : Qc[j] * piv;
+#pragma unroll
+                for (uint32_t r = 0; r < NX; ++r) Qc[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : Qc[r]);
+            }
+            if (j < NU) {
+                const T piv = T(1) / cr[j];
+                const T pr = is_j ? piv : Rc[j] * piv;
+#pragma unroll
+                for (uint32_t r = 0; r < NU; ++r) Rc[r] = (r == j) ? pr : fma_t(-cr[r], pr, is_j ? T(0) : Rc[r]);
+            }
+        }
+        // G^-1 in place of G (the write-out copies the region)
+        if (Ginv) {
+            if (l < NX) {
+#pragma unroll
+                for (uint32_t r = 0; r < NX; ++r) rQ[l * NX + r] = Qc[r];
+            }
+            if (l < NU) {
+#pragma unroll
+                for (uint32_t r = 0; r < NU; ++r) rR[l * NU + r] = Rc[r];
+            }
+        }
+        // [W | A e] = A [Q^-1 | e],  [V | B f] = B [R^-1 | f]
+        T Xc[NX], Yc[NX];
+#pragma unroll
+        for (uint32_t r = 0; r < NX; ++r) Xc[r] = Yc[r] = T(0);
+#pragma unroll
+        for (uint32_t q = 0; q < NX; ++q) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) Xc[r] = fma_t(rA[q * NX + r], Qc[q], Xc[r]);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < NU; ++q) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) Yc[r] = fma_t(rB[q * NX + r], Rc[q], Yc[r]);
+        }
+        T *wq = lds + Q::WSL + (qd + 1) * (NX + 1) * CP, *vq = lds + Q::VSL + (qd + 1) * (NU + 1) * CP, *tq = lds + Q::TSL + (qd + 1) * NX * CP;
+        if (l <= NX) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) wq[l * CP + r] = T(0) - Xc[r];
+        }
+        if (l <= NU) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) vq[l * CP + r] = Yc[r];
+        }
+        // row l of A and of B
+        T ar[NX], brow[NU];
+#pragma unroll
+        for (uint32_t q = 0; q < NX; ++q) ar[q] = rA[q * NX + (l < NX ? l : 0)];
+#pragma unroll
+        for (uint32_t q = 0; q < NU; ++q) brow[q] = rB[q * NX + (l < NX ? l : 0)];
+        wave_sync();
+        // T = W A' + V B'
+        T Tc[NX];
+#pragma unroll
+        for (uint32_t r = 0; r < NX; ++r) Tc[r] = T(0);
+#pragma unroll
+        for (uint32_t q = 0; q < NX; ++q) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) Tc[r] = fma_t(-wq[q * CP + r], ar[q], Tc[r]);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < NU; ++q) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) Tc[r] = fma_t(vq[q * CP + r], brow[q], Tc[r]);
+        }
+        if (l < NX) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) tq[l * CP + r] = Tc[r];
+        }
+        wave_sync();
+        // D_j = T_{j-1} + Q_j^-1;  gamma_j = -(c_j + e_j - (A e + B f)_{j-1})
+        const T *tp = tq - NX * CP, *wp = wq - (NX + 1) * CP, *vp = vq - (NU + 1) * CP;
+        if (l < NX) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) lds[Q::DSL + qd * NX * NX + l * NX + r] = tp[l * CP + r] + Qc[r];
+        }
+        if (l == NX) {
+#pragma unroll
+            for (uint32_t r = 0; r < NX; ++r) {
+                const T wprev = vp[NU * CP + r] - wp[NX * CP + r];
+                lds[Q::GAM + qd * NX + r] = -(raw[Q::Rc + qd * NX + r] + Qc[r] - wprev);
+            }
+        }
+        wave_sync();
+        if (emit) {
+            T *So = S + ((size_t)prob * N + jb) * Q::SROW;
+#pragma unroll
+            for (uint32_t t = 0; t < Q::OUT_T; ++t)
+                if (t * 64 + lane < 4 * Q::SROW) So[t * 64 + lane] = lds[src[t]];
+            if (lane < 4 * NX) gamma[((size_t)prob * N + jb) * NX + lane] = lds[Q::GAM + lane];
+            if (Ginv) {
+                T *Go = Ginv + (size_t)prob * d.szG + (size_t)jb * Q::SG;
+                const uint32_t lim = (uint32_t)(d.szG - (size_t)jb * Q::SG);
+                for (uint32_t i = lane; i < 4 * Q::SG && i < lim; i += 64) Go[i] = raw[Q::RG + i];
+            }
+        }
+        // carry: the last quarter's slots become slot 0 of the next step
+        for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + i] = lds[Q::WSL + 4 * (NX + 1) * CP + i];
+        for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + i] = lds[Q::TSL + 4 * NX * CP + i];
+        if (lane < CP) lds[Q::VSL + NU * CP + lane] = lds[Q::VSL + 4 * (NU + 1) * CP + NU * CP + lane];
+        wave_sync();
+    }
+}
+
 // z = -G^-1 (g + C' lambda): x_k = -Q_k^-1 (q_k + lambda_k - A_k' lambda_{k+1}),  u_k = -R_k^-1 (r_k - B_k' lambda_{k+1}).
 template <typename T>
 __global__ __launch_bounds__(256) void schur_recover_kernel(uint32_t nx, uint32_t nu, uint32_t N, uint64_t rows,
@@ -275,6 +529,24 @@ template <typename T>
 hipError_t launch_form_schur(const DeviceInfo &dev, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *G, const T *C,
                              const T *g, const T *c, T *S, T *gamma, T *Ginv, hipStream_t s)
 {
+    // GBDPCG_SCHUR_GENERAL=1: the any-size kernel also where the four-knots-per-wave form exists (A/B runs, tests)
+    const char *env = getenv("GBDPCG_SCHUR_GENERAL");
+    if (nx == 14 && nu == 7 && N % 4 == 0 && !(env && env[0] == '1')) {
+        using Q = QuadGeom<T, 14, 7>;
+        // one run per problem when the batch alone fills the device, shorter runs (each pays one silent step) otherwise
+        uint32_t run = N;
+        while (run % 8 == 0 && (uint64_t)batch * (N / run) < 4ull * dev.num_cus) run /= 2;
+        const uint64_t nwaves = (uint64_t)batch * (N / run);
+        if (nwaves > 0x7fffffffull) return hipErrorInvalidValue;
+        const size_t lds = (size_t)Q::TOTAL * sizeof(T);
+        auto kern = schur_form_quad_kernel<T, 14, 7>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((uint32_t)nwaves), dim3(64), lds, s, N, run, (uint32_t)nwaves, G, C, g, c, S, gamma, Ginv);
+        return hipGetLastError();
+    }
     const size_t wave_bytes = (size_t)schur_wave_elems(nx, nu) * sizeof(T);
     const uint32_t waves = waves_for(dev, wave_bytes);
     if (!waves) return hipErrorInvalidValue;

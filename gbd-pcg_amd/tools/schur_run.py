@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Times the two steps either side of the solve (csrc/schur.hip) next to Pinv formation and the solve itself, on
+synthetic KKT blocks of the BASELINE batch shape:   python gbd-pcg_amd/tools/schur_run.py [--nx 14 --nu 7 --N 128 --batch 1024]
+Algorithmic bytes = every input once + every output once (form: G, C, g, c -> S, gamma, G^-1; recover: G^-1, C, g, lambda -> z).
+Inputs are drawn on the device (SPD cost blocks M M' + I, dynamics I + noise); event-timed, median of --reps."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gbd_pcg_amd import binding  # noqa: E402
+
+
+def kkt_on_device(nx, nu, N, B, dtype, seed=0):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    sg, sc, sv = nx * nx + nu * nu, nx * nx + nx * nu, nx + nu
+
+    def spd(m, count):
+        a = torch.randn(count, m, m, device="cuda", dtype=dtype, generator=gen) / m ** 0.5
+        return a @ a.transpose(1, 2) + torch.eye(m, device="cuda", dtype=dtype)
+
+    G = torch.zeros(B, N, sg, device="cuda", dtype=dtype)
+    G[:, :, :nx * nx] = spd(nx, B * N).reshape(B, N, -1)
+    G[:, :, nx * nx:] = spd(nu, B * N).reshape(B, N, -1)
+    G = G.reshape(B, -1)[:, :sg * N - nu * nu].contiguous()
+    C = torch.zeros(B, N - 1, sc, device="cuda", dtype=dtype)
+    A = torch.eye(nx, device="cuda", dtype=dtype) + 0.3 * torch.randn(B * (N - 1), nx, nx, device="cuda", dtype=dtype, generator=gen) / nx ** 0.5
+    C[:, :, :nx * nx] = A.transpose(1, 2).reshape(B, N - 1, -1)
+    C[:, :, nx * nx:] = (torch.randn(B, N - 1, nx * nu, device="cuda", dtype=dtype, generator=gen) / nx ** 0.5)
+    g = torch.randn(B, sv * N - nu, device="cuda", dtype=dtype, generator=gen)
+    c = 0.1 * torch.randn(B, nx * N, device="cuda", dtype=dtype, generator=gen)
+    return G.reshape(-1), C.reshape(-1), g.reshape(-1), c.reshape(-1)
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=14)
+    ap.add_argument("--nu", type=int, default=7)
+    ap.add_argument("--N", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--reps", type=int, default=30)
+    a = ap.parse_args()
+    dtype = torch.float32 if a.dtype == "f32" else torch.float64
+    es = 4 if a.dtype == "f32" else 8
+    nx, nu, N, B = a.nx, a.nu, a.N, a.batch
+    s = binding.Solver(0)
+    G, C, g, c = kkt_on_device(nx, nu, N, B, dtype)
+    S, gamma, Ginv = s.form_schur(nx, nu, N, B, G, C, g, c)
+    Pinv = torch.empty_like(S)
+    lam = torch.zeros_like(gamma)
+    z = torch.empty_like(g)
+    it, fl = s.form_pinv_solve(nx, N, B, S, Pinv, gamma, lam, tol=1e-6, max_iter=100)
+    torch.cuda.synchronize()
+    sym = bool(s.check_symmetric(nx, N, B, S).all())
+    out = {"shape": f"nx{nx} nu{nu} N{N} x{B} {a.dtype}", "S_symmetric_in_storage": sym, "iters_mean": float(it.float().mean()),
+           "max_iter_exits": int(fl.sum())}
+    by_form = (G.numel() * 2 + C.numel() + g.numel() + c.numel() + S.numel() + gamma.numel()) * es
+    by_rec = (Ginv.numel() + C.numel() + g.numel() + lam.numel() + z.numel()) * es
+    t = timed(lambda: s.form_schur(nx, nu, N, B, G, C, g, c, S=S, gamma=gamma, Ginv=Ginv), a.reps)
+    out["form_schur_us"] = round(t * 1e3, 1)
+    out["form_schur_GBps"] = round(by_form / t / 1e6, 0)
+    t = timed(lambda: s.form_pinv(nx, N, B, S, Pinv=Pinv), a.reps)
+    out["form_pinv_us"] = round(t * 1e3, 1)
+
+    def solve():
+        lam.zero_()
+        s.solve(nx, N, B, S, Pinv, gamma, lam, tol=1e-6, max_iter=100, iters=it, max_iter_exit=fl)
+    t = timed(solve, a.reps)
+    out["solve_converged_us"] = round(t * 1e3, 1)
+    t = timed(lambda: s.recover_primal(nx, nu, N, B, Ginv, C, g, lam, z=z), a.reps)
+    out["recover_primal_us"] = round(t * 1e3, 1)
+    out["recover_primal_GBps"] = round(by_rec / t / 1e6, 0)
+    print(json.dumps(out))
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

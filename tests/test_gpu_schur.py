@@ -67,6 +67,29 @@ def test_form_schur_blocks_wider_than_a_wavefront(solver):
     test_form_schur_and_recover_vs_oracle(solver, 66, 2, 3, 1, np.float32, 2e-4)
 
 
+def test_general_kernel_where_the_four_knot_form_exists(solver, monkeypatch):
+    """nx 14, nu 7, knotPoints % 4 == 0 normally takes schur_form_quad_kernel; GBDPCG_SCHUR_GENERAL=1 keeps the any-size kernel on
+    those shapes too.  Both against the oracle, and against each other to rounding."""
+    nx, nu, N, B = 14, 7, 32, 5
+    d = so.gen(nx, nu, N, seed=8, batch=B, dtype=np.float32)
+    dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
+    fast = [t.cpu().numpy() for t in solver.form_schur(nx, nu, N, B, dG, dC, dg, dc)]
+    monkeypatch.setenv("GBDPCG_SCHUR_GENERAL", "1")
+    test_form_schur_and_recover_vs_oracle(solver, nx, nu, N, B, np.float32, 2e-4)
+    gen = [t.cpu().numpy() for t in solver.form_schur(nx, nu, N, B, dG, dC, dg, dc)]
+    monkeypatch.delenv("GBDPCG_SCHUR_GENERAL")
+    for a, b in zip(fast, gen):
+        assert close(a, b, 1e-4) and not np.array_equal(a, b)   # two kernels: other summation order, no mirrored inverses
+
+
+@pytest.mark.parametrize("N,B", [(4, 1), (8, 3), (128, 2), (64, 40), (36, 7), (256, 1)])
+def test_four_knot_form_runs_of_every_length(solver, N, B):
+    """The walking kernel splits a problem into runs when the batch alone does not fill the device (each run starts with a silent
+    step on the four knots before it): one problem of 256 knots is 64 runs of 4, 40 problems of 64 knots 2 runs each, ..."""
+    for dtype, tol in ((np.float32, 2e-4), (np.float64, 1e-11)):
+        test_form_schur_and_recover_vs_oracle(solver, 14, 7, N, B, dtype, tol)
+
+
 def test_form_schur_without_ginv_and_bad_arguments(solver):
     nx, nu, N, B = 14, 7, 8, 2
     d = so.gen(nx, nu, N, seed=3, batch=B, dtype=np.float32)
