@@ -231,19 +231,56 @@ __device__ __forceinline__ void dma_dword(const void *base, uint32_t byte_off, u
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "v"(byte_off), "s"(lds_addr) : "memory");
 }
+// Sixteen of them for 4 KB that are contiguous in memory and in LDS: the instruction offset moves both addresses, so one M0
+// setting serves all (lane_off = 4 * lane).
+#define GBDPCG_DMA_AT(o) "global_load_lds_dword %2, %1 offset:" #o "\n\t"
+__device__ __forceinline__ void dma_4k(const void *base, uint32_t lane_off, uint32_t lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 GBDPCG_DMA_AT(0) GBDPCG_DMA_AT(256) GBDPCG_DMA_AT(512) GBDPCG_DMA_AT(768)
+                 GBDPCG_DMA_AT(1024) GBDPCG_DMA_AT(1280) GBDPCG_DMA_AT(1536) GBDPCG_DMA_AT(1792)
+                 GBDPCG_DMA_AT(2048) GBDPCG_DMA_AT(2304) GBDPCG_DMA_AT(2560) GBDPCG_DMA_AT(2816)
+                 GBDPCG_DMA_AT(3072) GBDPCG_DMA_AT(3328) GBDPCG_DMA_AT(3584) GBDPCG_DMA_AT(3840)
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(lane_off), "s"(lds_addr) : "memory");
+}
+#undef GBDPCG_DMA_AT
+// A region of DWORDS dwords (LDS room: the next multiple of 64), every lane of every instruction active: the caller has checked
+// that the bytes up to the padded end exist in memory.
+template <uint32_t DWORDS> __device__ __forceinline__ void dma_region(const void *base, uint32_t lane_off, uint32_t lds_addr)
+{
+    constexpr uint32_t INSTR = (DWORDS + 63) / 64;
+#pragma unroll
+    for (uint32_t i = 0; i + 16 <= INSTR; i += 16) dma_4k(static_cast<const char *>(base) + i * 256, lane_off, lds_addr + i * 256);
+#pragma unroll
+    for (uint32_t i = INSTR / 16 * 16; i < INSTR; ++i) dma_dword(static_cast<const char *>(base) + i * 256, lane_off, lds_addr + i * 256);
+}
+
+// 1 / x: the hardware reciprocal and one Newton step in fp32 (the division sequence is a dozen dependent instructions on the
+// critical path of every pivot step), the division in fp64.
+__device__ __forceinline__ float quad_rcp(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fma_t(fma_t(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double quad_rcp(double x) { return 1.0 / x; }
 
 template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t CP = 16;  // padded column
     static constexpr uint32_t SG = NX * NX + NU * NU, SC = NX * NX + NX * NU, SV = NX + NU;
     // raw inputs of one step (four knots), as they lie in memory
-    static constexpr uint32_t RG = 0, RC = RG + 4 * SG, Rg = RC + 4 * SC, Rc = Rg + 4 * SV, RAW = Rc + 4 * NX;
-    static constexpr uint32_t RAW_P = (RAW + 3) & ~3u;
+    // (each region padded to whole 256-byte DMA instructions)
+    static constexpr uint32_t DW = sizeof(T) / 4;
+    static constexpr uint32_t pad(uint32_t elems) { return (elems * DW + 63) / 64 * 64 / DW; }
+    static constexpr uint32_t RG = 0, RC = RG + pad(4 * SG), Rg = RC + pad(4 * SC), Rc = Rg + pad(4 * SV), RAW_P = Rc + pad(4 * NX);
     static constexpr uint32_t WSL = 2 * RAW_P;                    // 5 slots of (NX+1) padded columns: -[W_j | A e_j]
     static constexpr uint32_t TSL = WSL + 5 * (NX + 1) * CP;      // 5 slots of NX padded columns: T_j
     static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of (NU+1) padded columns: [V_j | B f_j]
     static constexpr uint32_t DSL = VSL + 5 * (NU + 1) * CP;      // 4 x NX*NX: D_j, unpadded column-major
     static constexpr uint32_t BCQ = DSL + 4 * NX * NX, BCR = BCQ + 4 * CP, GAM = BCR + 4 * CP;
-    static constexpr uint32_t TOTAL = (GAM + 4 * NX + 3) & ~3u;
+    static constexpr uint32_t ZER = (GAM + 4 * NX + 3) & ~3u;      // CP zeros: the "columns" of the lanes that own none
+    static constexpr uint32_t TOTAL = ZER + CP;
     static constexpr uint32_t SROW = 3 * NX * NX;
     static constexpr uint32_t OUT_T = (4 * SROW + 63) / 64;       // trips of the S write-out
 };
@@ -285,10 +322,26 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + i] = T(0);
     for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + i] = T(0);
     for (uint32_t i = lane; i < (NU + 1) * CP; i += 64) lds[Q::VSL + i] = T(0);
+    if (lane < CP) lds[Q::ZER + lane] = T(0);
 
     // requests for the four knots from jb on into raw buffer b (elements past the end of the problem's arrays are not requested)
+    const uint32_t batch = waves / rpp;
     auto request = [&](uint32_t jb, uint32_t b) {
         const uint32_t base = (uint32_t)(uintptr_t)(lds + b * Q::RAW_P);
+        {
+            // whole instructions while the bytes up to each padded end lie inside the arrays (what is read past a problem's own
+            // end -- the R, A, B, r its last knot does not have -- is the next problem's data and is overwritten below)
+            const size_t eG = (size_t)prob * d.szG + (size_t)jb * Q::SG + Q::pad(4 * Q::SG), eC = (size_t)prob * d.szC + (size_t)jb * Q::SC + Q::pad(4 * Q::SC);
+            const size_t eg = (size_t)prob * d.szg + (size_t)jb * Q::SV + Q::pad(4 * Q::SV), ec = (size_t)prob * d.szc + (size_t)jb * NX + Q::pad(4 * NX);
+            if (eG <= (size_t)batch * d.szG && eC <= (size_t)batch * d.szC && eg <= (size_t)batch * d.szg && ec <= (size_t)batch * d.szc) {
+                const uint32_t lo = lane * 4;
+                dma_region<4 * Q::SG * DW>(Gp + (size_t)jb * Q::SG, lo, base + Q::RG * DW * 4);
+                dma_region<4 * Q::SC * DW>(Cp + (size_t)jb * Q::SC, lo, base + Q::RC * DW * 4);
+                dma_region<4 * Q::SV * DW>(gp + (size_t)jb * Q::SV, lo, base + Q::Rg * DW * 4);
+                dma_region<4 * NX * DW>(cp + (size_t)jb * NX, lo, base + Q::Rc * DW * 4);
+                return;
+            }
+        }
         const uint32_t lim_G = (uint32_t)(d.szG - (size_t)jb * Q::SG) * DW, lim_C = jb < N - 1 ? (uint32_t)(d.szC - (size_t)jb * Q::SC) * DW : 0u;
         const uint32_t lim_g = (uint32_t)(d.szg - (size_t)jb * Q::SV) * DW;
         const T *sG = Gp + (size_t)jb * Q::SG, *sC = Cp + (size_t)jb * Q::SC, *sg = gp + (size_t)jb * Q::SV, *sc = cp + (size_t)jb * NX;
@@ -312,7 +365,12 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     uint32_t b = 0;
     for (uint32_t jb = j_first; jb < j_end; jb += 4, b ^= 1u) {
         const bool emit = jb >= j_start;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // The requests for this step were issued before the previous step's stores (at least OUT_T + 1 of them, one instruction
+        // each, when it stored at all) and memory operations of a wave retire in order: waiting until 32 are left is waiting
+        // for the requests without waiting for the stores.
+        static_assert(Q::OUT_T + 1 >= 32, "fewer stores per step than the wait below leaves in flight");
+        if (jb > j_start) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (jb + 4 < j_end) request(jb + 4, b ^ 1u);
         T *raw = lds + b * Q::RAW_P;
         T *rQ = raw + Q::RG + qd * Q::SG, *rR = rQ + NX * NX, *rA = raw + Q::RC + qd * Q::SC, *rB = rA + NX * NX;
@@ -325,10 +383,15 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         wave_sync();
         // this lane's columns: Q_j (lane NX: q_j), R_j (lane NU: r_j)
         T Qc[NX], Rc[NU];
+        {
+            const T *zero = lds + Q::ZER;
+            const T *pq = l < NX ? rQ + l * NX : (l == NX ? raw + Q::Rg + qd * Q::SV : zero);
+            const T *pr = l < NU ? rR + l * NU : (l == NU ? raw + Q::Rg + qd * Q::SV + NX : zero);
 #pragma unroll
-        for (uint32_t r = 0; r < NX; ++r) Qc[r] = l < NX ? rQ[l * NX + r] : (l == NX ? raw[Q::Rg + qd * Q::SV + r] : T(0));
+            for (uint32_t r = 0; r < NX; ++r) Qc[r] = pq[r];
 #pragma unroll
-        for (uint32_t r = 0; r < NU; ++r) Rc[r] = l < NU ? rR[l * NU + r] : (l == NU ? raw[Q::Rg + qd * Q::SV + NX + r] : T(0));
+            for (uint32_t r = 0; r < NU; ++r) Rc[r] = pr[r];
+        }
         T *bq = lds + Q::BCQ + qd * CP, *br = lds + Q::BCR + qd * CP;
 #pragma unroll
         for (uint32_t j = 0; j < NX; ++j) {
@@ -351,13 +414,13 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
             wave_sync();  // everyone has the columns before step j+1 overwrites them
             const bool is_j = l == j;
             {
-                const T piv = T(1) / cj[j];
+                const T piv = quad_rcp(cj[j]);
                 const T pr = is_j ? piv : Qc[j] * piv;
 #pragma unroll
                 for (uint32_t r = 0; r < NX; ++r) Qc[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : Qc[r]);
             }
             if (j < NU) {
-                const T piv = T(1) / cr[j];
+                const T piv = quad_rcp(cr[j]);
                 const T pr = is_j ? piv : Rc[j] * piv;
 #pragma unroll
                 for (uint32_t r = 0; r < NU; ++r) Rc[r] = (r == j) ? pr : fma_t(-cr[r], pr, is_j ? T(0) : Rc[r]);
