@@ -28,6 +28,16 @@
 #include "bt_device.hpp"
 #include "internal.hpp"
 
+#ifndef GBDPCG_SCHUR_SKIP
+#define GBDPCG_SCHUR_SKIP 0   // timing builds only: 1 no elimination, 2 no products, 4 no stores, 8 no requests after the first (results are wrong)
+#endif
+
+#ifdef GBDPCG_SCHUR_STAMPS   // timing builds only: s_memtime at the phase boundaries of one step of workgroup 0, left in the tail of gamma
+#define SCHUR_STAMP(i) do { if (stamp_now) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st[i] = t_; } } while (0)
+#else
+#define SCHUR_STAMP(i) do { } while (0)
+#endif
+
 namespace gbdpcg {
 
 namespace {
@@ -266,6 +276,44 @@ __device__ __forceinline__ float quad_rcp(float x)
 }
 __device__ __forceinline__ double quad_rcp(double x) { return 1.0 / x; }
 
+// The value lane J of every 16-lane row holds, in all lanes of that row: ds_swizzle in bit-mask mode (lane' = (lane & 0x10) | J
+// inside each half of the wave) -- the LDS crossbar without LDS memory, one trip instead of the write + read of a broadcast line.
+template <int J> __device__ __forceinline__ float row_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x10 | (J << 5)));
+}
+template <int J> __device__ __forceinline__ double row_bcast(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffll), 0x10 | (J << 5));
+    const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x10 | (J << 5));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// One pivot step of the in-place Gauss-Jordan elimination on an M x M block held one column per lane (pinv_diag_quad_kernel's
+// arithmetic): J is the pivot.
+template <int J, int M, typename T> __device__ __forceinline__ void quad_pivot(T (&col)[M], uint32_t l)
+{
+    T cj[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) cj[r] = row_bcast<J>(col[r]);
+    const bool is_j = l == (uint32_t)J;
+    const T piv = quad_rcp(cj[J]);
+    const T pr = is_j ? piv : col[J] * piv;
+#pragma unroll
+    for (int r = 0; r < M; ++r) col[r] = (r == J) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+}
+// between(J) runs after pivot J: the caller spreads the previous step's stores over the elimination with it.
+template <int J, int NX, int NU, typename T, typename F>
+__device__ __forceinline__ void quad_eliminate(T (&Qc)[NX], T (&Rc)[NU], uint32_t l, F &&between)
+{
+    if constexpr (J < NX) {
+        quad_pivot<J, NX>(Qc, l);
+        if constexpr (J < NU) quad_pivot<J, NU>(Rc, l);
+        between(J);
+        quad_eliminate<J + 1, NX, NU>(Qc, Rc, l, between);
+    }
+}
+
 template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t CP = 16;  // padded column
     static constexpr uint32_t SG = NX * NX + NU * NU, SC = NX * NX + NX * NU, SV = NX + NU;
@@ -278,7 +326,7 @@ template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t TSL = WSL + 5 * (NX + 1) * CP;      // 5 slots of NX padded columns: T_j
     static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of (NU+1) padded columns: [V_j | B f_j]
     static constexpr uint32_t DSL = VSL + 5 * (NU + 1) * CP;      // 4 x NX*NX: D_j, unpadded column-major
-    static constexpr uint32_t BCQ = DSL + 4 * NX * NX, BCR = BCQ + 4 * CP, GAM = BCR + 4 * CP;
+    static constexpr uint32_t GAM = DSL + 4 * NX * NX;
     static constexpr uint32_t ZER = (GAM + 4 * NX + 3) & ~3u;      // CP zeros: the "columns" of the lanes that own none
     static constexpr uint32_t TOTAL = ZER + CP;
     static constexpr uint32_t SROW = 3 * NX * NX;
@@ -319,9 +367,10 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
                              : Q::WSL + (q + 1) * (NX + 1) * CP + r * CP + cc;
     }
     // carry slots of a run that starts a problem: L_0 = 0, D_0 = Q_0^-1, gamma_0 = -(c_0 + Q_0^-1 q_0)
-    for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + i] = T(0);
-    for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + i] = T(0);
-    for (uint32_t i = lane; i < (NU + 1) * CP; i += 64) lds[Q::VSL + i] = T(0);
+    // (written into the last quarter's slots: every step begins by moving those into slot 0)
+    for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + 4 * (NX + 1) * CP + i] = T(0);
+    for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + 4 * NX * CP + i] = T(0);
+    for (uint32_t i = lane; i < (NU + 1) * CP; i += 64) lds[Q::VSL + 4 * (NU + 1) * CP + i] = T(0);
     if (lane < CP) lds[Q::ZER + lane] = T(0);
 
     // requests for the four knots from jb on into raw buffer b (elements past the end of the problem's arrays are not requested)
@@ -362,16 +411,34 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     const bool pre = j_start != 0;                     // one silent step on the four knots before the run
     const uint32_t j_first = pre ? j_start - 4 : j_start, j_end = j_start + run;
     request(j_first, 0);
-    uint32_t b = 0;
+    uint32_t b = 0, stores_since_request = 0;
+    bool pending = false;   // S / gamma of the previous step still sit in LDS
+    T *So_prev = S, *gam_prev = gamma;
+#ifdef GBDPCG_SCHUR_STAMPS
+    unsigned long long st[12] = {};
+#endif
+    constexpr uint32_t GI_T = (4 * Q::SG + 63) / 64;
     for (uint32_t jb = j_first; jb < j_end; jb += 4, b ^= 1u) {
         const bool emit = jb >= j_start;
-        // The requests for this step were issued before the previous step's stores (at least OUT_T + 1 of them, one instruction
-        // each, when it stored at all) and memory operations of a wave retire in order: waiting until 32 are left is waiting
-        // for the requests without waiting for the stores.
-        static_assert(Q::OUT_T + 1 >= 32, "fewer stores per step than the wait below leaves in flight");
-        if (jb > j_start) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (jb + 4 < j_end) request(jb + 4, b ^ 1u);
+#ifdef GBDPCG_SCHUR_STAMPS
+        const bool stamp_now = blockIdx.x == 0 && jb == 20;
+#endif
+        SCHUR_STAMP(0);
+        // The requests for this step were issued at the top of the previous one, before every store that step issued (the
+        // deferred S / gamma stores of the step before it: OUT_T + 1 instructions, and its own G^-1 stores: GI_T -- one
+        // instruction per trip, which is why the write-out loops are written trip by trip), and the memory operations of a wave
+        // retire in order: waiting until exactly that many are left is waiting for the requests and for nothing else.
+        static_assert(Q::OUT_T + 1 + GI_T <= 63, "vmcnt is a 6-bit counter");
+        switch (GBDPCG_SCHUR_SKIP & 4 ? 0u : stores_since_request) {
+        case Q::OUT_T + 1 + GI_T: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Q::OUT_T + 1 + GI_T) : "memory"); break;
+        case Q::OUT_T + 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Q::OUT_T + 1) : "memory"); break;
+        case GI_T: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GI_T) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+        stores_since_request = 0;
+        SCHUR_STAMP(1);
+        if (jb + 4 < j_end && !(GBDPCG_SCHUR_SKIP & 8)) request(jb + 4, b ^ 1u);
+        SCHUR_STAMP(2);
         T *raw = lds + b * Q::RAW_P;
         T *rQ = raw + Q::RG + qd * Q::SG, *rR = rQ + NX * NX, *rA = raw + Q::RC + qd * Q::SC, *rB = rA + NX * NX;
         if (jb + 4 == N) {  // the last knot has no R, A, B, r in memory: R = I, the rest 0 (W = V = 0: R_{N-1} = 0)
@@ -392,40 +459,53 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #pragma unroll
             for (uint32_t r = 0; r < NU; ++r) Rc[r] = pr[r];
         }
-        T *bq = lds + Q::BCQ + qd * CP, *br = lds + Q::BCR + qd * CP;
+        SCHUR_STAMP(3);
+        // S and gamma of the PREVIOUS step leave now, a few stores after every pivot: all waves of the device walk in step, and
+        // stores issued in one piece at the end of a step reach the memory system as one burst (14 MB) that the next requests
+        // then queue behind
+        constexpr uint32_t PER = (Q::OUT_T + NX - 2) / (NX - 1);
+        static_assert(PER * (NX - 1) >= Q::OUT_T, "the last pivot's slot is gamma's");
+        T outv[Q::OUT_T + 1];
+        if (pending) {   // one round trip for all of them, before the slots are touched
 #pragma unroll
-        for (uint32_t j = 0; j < NX; ++j) {
-            if (l == j) {
-#pragma unroll
-                for (uint32_t r = 0; r < NX; ++r) bq[r] = Qc[r];
-                if (j < NU) {
-#pragma unroll
-                    for (uint32_t r = 0; r < NU; ++r) br[r] = Rc[r];
-                }
-            }
-            wave_sync();
-            T cj[NX], cr[NU];
-#pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) cj[r] = bq[r];
-            if (j < NU) {
-#pragma unroll
-                for (uint32_t r = 0; r < NU; ++r) cr[r] = br[r];
-            }
-            wave_sync();  // everyone has the columns before step j+1 overwrites them
-            const bool is_j = l == j;
-            {
-                const T piv = quad_rcp(cj[j]);
-                const T pr = is_j ? piv : Qc[j] * piv;
-#pragma unroll
-                for (uint32_t r = 0; r < NX; ++r) Qc[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : Qc[r]);
-            }
-            if (j < NU) {
-                const T piv = quad_rcp(cr[j]);
-                const T pr = is_j ? piv : Rc[j] * piv;
-#pragma unroll
-                for (uint32_t r = 0; r < NU; ++r) Rc[r] = (r == j) ? pr : fma_t(-cr[r], pr, is_j ? T(0) : Rc[r]);
-            }
+            for (uint32_t t = 0; t < Q::OUT_T; ++t) outv[t] = lds[src[t]];
+            outv[Q::OUT_T] = lds[Q::GAM + (lane < 4 * NX ? lane : 0u)];
+            stores_since_request += Q::OUT_T + 1;
         }
+        auto drain = [&](uint32_t J) {
+#pragma unroll
+            for (uint32_t t = J * PER; t < (J + 1) * PER && t < Q::OUT_T; ++t)
+                if (J + 1 < NX && t * 64 + lane < 4 * Q::SROW) So_prev[t * 64 + lane] = outv[t];
+            if (J + 1 == NX && lane < 4 * NX) gam_prev[lane] = outv[Q::OUT_T];
+        };
+        if (!(GBDPCG_SCHUR_SKIP & 1)) {
+            if (pending) quad_eliminate<0, NX, NU>(Qc, Rc, l, drain);
+            else quad_eliminate<0, NX, NU>(Qc, Rc, l, [](uint32_t) {});
+        } else if (pending) {
+#pragma unroll
+            for (uint32_t J = 0; J < NX; ++J) drain(J);
+        }
+        SCHUR_STAMP(4);
+        // carry: the last quarter's slots of the previous step become slot 0 of this one (reads first, then writes: the
+        // compiler must assume that one LDS write changes what the next LDS read sees and will not batch them itself)
+        {
+            constexpr uint32_t WT = ((NX + 1) * CP + 63) / 64, TT = (NX * CP + 63) / 64;
+            T cw[WT], ct[TT];
+#pragma unroll
+            for (uint32_t t = 0; t < WT; ++t) cw[t] = lds[Q::WSL + 4 * (NX + 1) * CP + (t * 64 + lane < (NX + 1) * CP ? t * 64 + lane : 0u)];
+#pragma unroll
+            for (uint32_t t = 0; t < TT; ++t) ct[t] = lds[Q::TSL + 4 * NX * CP + (t * 64 + lane < NX * CP ? t * 64 + lane : 0u)];
+            const T cv = lds[Q::VSL + 4 * (NU + 1) * CP + NU * CP + (lane & (CP - 1))];
+#pragma unroll
+            for (uint32_t t = 0; t < WT; ++t)
+                if (t * 64 + lane < (NX + 1) * CP) lds[Q::WSL + t * 64 + lane] = cw[t];
+#pragma unroll
+            for (uint32_t t = 0; t < TT; ++t)
+                if (t * 64 + lane < NX * CP) lds[Q::TSL + t * 64 + lane] = ct[t];
+            if (lane < CP) lds[Q::VSL + NU * CP + lane] = cv;
+        }
+        wave_sync();
+        SCHUR_STAMP(5);
         // G^-1 in place of G (the write-out copies the region)
         if (Ginv) {
             if (l < NX) {
@@ -442,12 +522,12 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #pragma unroll
         for (uint32_t r = 0; r < NX; ++r) Xc[r] = Yc[r] = T(0);
 #pragma unroll
-        for (uint32_t q = 0; q < NX; ++q) {
+        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NX); ++q) {
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) Xc[r] = fma_t(rA[q * NX + r], Qc[q], Xc[r]);
         }
 #pragma unroll
-        for (uint32_t q = 0; q < NU; ++q) {
+        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NU); ++q) {
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) Yc[r] = fma_t(rB[q * NX + r], Rc[q], Yc[r]);
         }
@@ -460,6 +540,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) vq[l * CP + r] = Yc[r];
         }
+        SCHUR_STAMP(6);
         // row l of A and of B
         T ar[NX], brow[NU];
 #pragma unroll
@@ -472,12 +553,12 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #pragma unroll
         for (uint32_t r = 0; r < NX; ++r) Tc[r] = T(0);
 #pragma unroll
-        for (uint32_t q = 0; q < NX; ++q) {
+        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NX); ++q) {
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) Tc[r] = fma_t(-wq[q * CP + r], ar[q], Tc[r]);
         }
 #pragma unroll
-        for (uint32_t q = 0; q < NU; ++q) {
+        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NU); ++q) {
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) Tc[r] = fma_t(vq[q * CP + r], brow[q], Tc[r]);
         }
@@ -486,38 +567,73 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
             for (uint32_t r = 0; r < NX; ++r) tq[l * CP + r] = Tc[r];
         }
         wave_sync();
+        SCHUR_STAMP(7);
         // D_j = T_{j-1} + Q_j^-1;  gamma_j = -(c_j + e_j - (A e + B f)_{j-1})
         const T *tp = tq - NX * CP, *wp = wq - (NX + 1) * CP, *vp = vq - (NU + 1) * CP;
-        if (l < NX) {
-#pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) lds[Q::DSL + qd * NX * NX + l * NX + r] = tp[l * CP + r] + Qc[r];
-        }
-        if (l == NX) {
+        {   // (reads first, then writes, as above)
+            T tv[NX], cv[NX], wv[NX], vv[NX];
+            const uint32_t lc = l < NX ? l : 0u;
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) {
-                const T wprev = vp[NU * CP + r] - wp[NX * CP + r];
-                lds[Q::GAM + qd * NX + r] = -(raw[Q::Rc + qd * NX + r] + Qc[r] - wprev);
+                tv[r] = tp[lc * CP + r];
+                cv[r] = raw[Q::Rc + qd * NX + r];
+                wv[r] = wp[NX * CP + r];
+                vv[r] = vp[NU * CP + r];
+            }
+            if (l < NX) {
+#pragma unroll
+                for (uint32_t r = 0; r < NX; ++r) lds[Q::DSL + qd * NX * NX + l * NX + r] = tv[r] + Qc[r];
+            }
+            if (l == NX) {
+#pragma unroll
+                for (uint32_t r = 0; r < NX; ++r) lds[Q::GAM + qd * NX + r] = -(cv[r] + Qc[r] - (vv[r] - wv[r]));
             }
         }
         wave_sync();
-        if (emit) {
-            T *So = S + ((size_t)prob * N + jb) * Q::SROW;
-#pragma unroll
-            for (uint32_t t = 0; t < Q::OUT_T; ++t)
-                if (t * 64 + lane < 4 * Q::SROW) So[t * 64 + lane] = lds[src[t]];
-            if (lane < 4 * NX) gamma[((size_t)prob * N + jb) * NX + lane] = lds[Q::GAM + lane];
+        SCHUR_STAMP(8);
+        pending = emit && !((GBDPCG_SCHUR_SKIP & 4) && jb != 0);
+        if (pending) {
+            So_prev = S + ((size_t)prob * N + jb) * Q::SROW;
+            gam_prev = gamma + ((size_t)prob * N + jb) * NX;
             if (Ginv) {
                 T *Go = Ginv + (size_t)prob * d.szG + (size_t)jb * Q::SG;
                 const uint32_t lim = (uint32_t)(d.szG - (size_t)jb * Q::SG);
-                for (uint32_t i = lane; i < 4 * Q::SG && i < lim; i += 64) Go[i] = raw[Q::RG + i];
+                if (lim >= 4 * Q::SG) {   // every step but a problem's last: whole trips, the reads in one batch
+                    T gv[GI_T];
+#pragma unroll
+                    for (uint32_t t = 0; t < GI_T; ++t) gv[t] = raw[Q::RG + t * 64 + lane];
+#pragma unroll
+                    for (uint32_t t = 0; t < GI_T; ++t)
+                        if (t * 64 + lane < 4 * Q::SG) Go[t * 64 + lane] = gv[t];
+                } else {
+#pragma unroll
+                    for (uint32_t t = 0; t < GI_T; ++t)
+                        if (t * 64 + lane < lim) Go[t * 64 + lane] = raw[Q::RG + t * 64 + lane];
+                }
+                stores_since_request += GI_T;
             }
         }
-        // carry: the last quarter's slots become slot 0 of the next step
-        for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + i] = lds[Q::WSL + 4 * (NX + 1) * CP + i];
-        for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + i] = lds[Q::TSL + 4 * NX * CP + i];
-        if (lane < CP) lds[Q::VSL + NU * CP + lane] = lds[Q::VSL + 4 * (NU + 1) * CP + NU * CP + lane];
-        wave_sync();
+#ifdef GBDPCG_SCHUR_STAMPS
+        {
+            const bool stamp_now = blockIdx.x == 0 && jb == 20;
+            SCHUR_STAMP(9);
+        }
+#endif
     }
+    // S and gamma of the last step
+    if (pending) {
+#pragma unroll
+        for (uint32_t t = 0; t < Q::OUT_T; ++t)
+            if (t * 64 + lane < 4 * Q::SROW) So_prev[t * 64 + lane] = lds[src[t]];
+        if (lane < 4 * NX) gam_prev[lane] = lds[Q::GAM + lane];
+    }
+#ifdef GBDPCG_SCHUR_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(gamma + (size_t)(waves / rpp) * N * NX) - 12;
+        for (int i = 0; i < 12; ++i) out[i] = st[i];
+    }
+#endif
 }
 
 // z = -G^-1 (g + C' lambda): x_k = -Q_k^-1 (q_k + lambda_k - A_k' lambda_{k+1}),  u_k = -R_k^-1 (r_k - B_k' lambda_{k+1}).

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--stamps", action="store_true", help="library built with -DGBDPCG_SCHUR_STAMPS: phase boundaries of one step")
     a = ap.parse_args()
     dtype = torch.float32 if a.dtype == "f32" else torch.float64
     es = 4 if a.dtype == "f32" else 8
@@ -89,6 +90,14 @@ def main():
     t = timed(lambda: s.recover_primal(nx, nu, N, B, Ginv, C, g, lam, z=z), a.reps)
     out["recover_primal_us"] = round(t * 1e3, 1)
     out["recover_primal_GBps"] = round(by_rec / t / 1e6, 0)
+    if a.stamps:
+        s.form_schur(nx, nu, N, B, G, C, g, c, S=S, gamma=gamma, Ginv=Ginv)
+        torch.cuda.synchronize()
+        st = gamma[-24:].view(torch.int64).cpu().tolist()[:10]
+        names = ["wait for the requests", "issue next requests", "fix-ups + sync", "columns into registers", "elimination + previous S stores",
+                 "carry", "W, V products", "rows + T product", "D, gamma", "G^-1 stores"]
+        out["stamps_cycles_100MHz"] = {names[i]: st[i + 1] - st[i] for i in range(9)}
+        out["stamps_step_total"] = st[9] - st[0]
     print(json.dumps(out))
     s.close()
 
