@@ -348,6 +348,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     T *lds = reinterpret_cast<T *>(smem_raw);
     uint32_t lane = threadIdx.x;
     asm volatile("" : "+v"(lane));
+    __builtin_assume(lane < 64);   // or every "trip * 64 + lane < size" below is a compare, an exec mask and a branch
     const uint32_t l = lane & 15u, qd = lane >> 4;
     const uint32_t w = blockIdx.x;
     if (w >= waves) return;

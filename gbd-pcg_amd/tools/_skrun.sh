@@ -1,4 +1,4 @@
-for v in "" sk1 sk2 sk4 sk8 sk3 sk7 sk15; do
+for v in "" stag0 stag100; do
   if [ -z "$v" ]; then unset GBDPCG_LIB; else export GBDPCG_LIB=$PWD/gbd-pcg_amd/csrc/variants/libgbdpcg_$v.so; fi
   echo "== ${v:-base}"; timeout -k 10 120 python gbd-pcg_amd/tools/schur_run.py --reps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['form_schur_us'])" || true
 done
