@@ -276,17 +276,18 @@ __device__ __forceinline__ float quad_rcp(float x)
 }
 __device__ __forceinline__ double quad_rcp(double x) { return 1.0 / x; }
 
-// The value lane J of every 16-lane row holds, in all lanes of that row: ds_swizzle in bit-mask mode (lane' = (lane & 0x10) | J
-// inside each half of the wave) -- the LDS crossbar without LDS memory, one trip instead of the write + read of a broadcast line.
+// The value lane J of every 16-lane row holds, in all lanes of that row: the DPP control row_newbcast (gfx90a and later) --
+// a VALU move, no trip through the LDS crossbar (ds_swizzle in bit-mask mode does the same at an LDS instruction's cost:
+// 294 of them per step and wave, on a pipe the four waves of a compute unit share).
 template <int J> __device__ __forceinline__ float row_bcast(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x10 | (J << 5)));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, false));
 }
 template <int J> __device__ __forceinline__ double row_bcast(double v)
 {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffll), 0x10 | (J << 5));
-    const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x10 | (J << 5));
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + J, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 // One pivot step of the in-place Gauss-Jordan elimination on an M x M block held one column per lane (pinv_diag_quad_kernel's
