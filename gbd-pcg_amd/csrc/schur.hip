@@ -281,15 +281,45 @@ __device__ __forceinline__ double quad_rcp(double x) { return 1.0 / x; }
 // 294 of them per step and wave, on a pipe the four waves of a compute unit share).
 template <int J> __device__ __forceinline__ float row_bcast(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, true));
 }
 template <int J> __device__ __forceinline__ double row_bcast(double v)
 {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + J, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + J, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// acc[r] += (src[r] of lane q of the row) * coef[q] for q in [Q0, QN): a block product whose left factor lives one column per
+// lane and whose right factor's column this lane holds in coef -- the broadcast rides on the fma as a DPP operand.
+// (v_fmac_*_dpp written out: hipcc pairs the fmas into v_pk_fma_f32, which takes no DPP operand, and keeps a v_mov_b32_dpp per
+// element next to them.  A VGPR a DPP operand reads must not have been written by the two preceding VALU instructions;
+// the compiler does not look into asm for that, so every chain starts behind an s_nop and reads registers no instruction of
+// the chain writes.)
+template <int J> __device__ __forceinline__ void fmac_bcast(float &acc, float src, float coef)
+{
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef), "n"(J));
+}
+template <int J> __device__ __forceinline__ void fmac_bcast(double &acc, double src, double coef)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef), "n"(J));
+}
+template <int Q0, int QN, int M, int K, typename T>
+__device__ __forceinline__ void bcast_mac_chain(const T (&src)[M], const T (&coef)[K], T (&acc)[M])
+{
+    if constexpr (Q0 < QN) {
+#pragma unroll
+        for (int r = 0; r < M; ++r) fmac_bcast<Q0>(acc[r], src[r], coef[Q0]);
+        bcast_mac_chain<Q0 + 1, QN, M, K>(src, coef, acc);
+    }
+}
+template <int Q0, int QN, int M, int K, typename T>
+__device__ __forceinline__ void bcast_mac(const T (&src)[M], const T (&coef)[K], T (&acc)[M])
+{
+    asm volatile("s_nop 1");
+    bcast_mac_chain<Q0, QN, M, K>(src, coef, acc);
+}
+
 // One pivot step of the in-place Gauss-Jordan elimination on an M x M block held one column per lane (pinv_diag_quad_kernel's
 // arithmetic): J is the pivot.
 template <int J, int M, typename T> __device__ __forceinline__ void quad_pivot(T (&col)[M], uint32_t l)
@@ -325,8 +355,8 @@ template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t RG = 0, RC = RG + pad(4 * SG), Rg = RC + pad(4 * SC), Rc = Rg + pad(4 * SV), RAW_P = Rc + pad(4 * NX);
     static constexpr uint32_t WSL = 2 * RAW_P;                    // 5 slots of (NX+1) padded columns: -[W_j | A e_j]
     static constexpr uint32_t TSL = WSL + 5 * (NX + 1) * CP;      // 5 slots of NX padded columns: T_j
-    static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of (NU+1) padded columns: [V_j | B f_j]
-    static constexpr uint32_t DSL = VSL + 5 * (NU + 1) * CP;      // 4 x NX*NX: D_j, unpadded column-major
+    static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of one padded column: B f_j
+    static constexpr uint32_t DSL = VSL + 5 * CP;                 // 4 x NX*NX: D_j, unpadded column-major
     static constexpr uint32_t GAM = DSL + 4 * NX * NX;
     static constexpr uint32_t ZER = (GAM + 4 * NX + 3) & ~3u;      // CP zeros: the "columns" of the lanes that own none
     static constexpr uint32_t TOTAL = ZER + CP;
@@ -372,7 +402,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     // (written into the last quarter's slots: every step begins by moving those into slot 0)
     for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + 4 * (NX + 1) * CP + i] = T(0);
     for (uint32_t i = lane; i < NX * CP; i += 64) lds[Q::TSL + 4 * NX * CP + i] = T(0);
-    for (uint32_t i = lane; i < (NU + 1) * CP; i += 64) lds[Q::VSL + 4 * (NU + 1) * CP + i] = T(0);
+    if (lane < CP) lds[Q::VSL + 4 * CP + lane] = T(0);
     if (lane < CP) lds[Q::ZER + lane] = T(0);
 
     // requests for the four knots from jb on into raw buffer b (elements past the end of the problem's arrays are not requested)
@@ -497,14 +527,14 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
             for (uint32_t t = 0; t < WT; ++t) cw[t] = lds[Q::WSL + 4 * (NX + 1) * CP + (t * 64 + lane < (NX + 1) * CP ? t * 64 + lane : 0u)];
 #pragma unroll
             for (uint32_t t = 0; t < TT; ++t) ct[t] = lds[Q::TSL + 4 * NX * CP + (t * 64 + lane < NX * CP ? t * 64 + lane : 0u)];
-            const T cv = lds[Q::VSL + 4 * (NU + 1) * CP + NU * CP + (lane & (CP - 1))];
+            const T cv = lds[Q::VSL + 4 * CP + (lane & (CP - 1))];
 #pragma unroll
             for (uint32_t t = 0; t < WT; ++t)
                 if (t * 64 + lane < (NX + 1) * CP) lds[Q::WSL + t * 64 + lane] = cw[t];
 #pragma unroll
             for (uint32_t t = 0; t < TT; ++t)
                 if (t * 64 + lane < NX * CP) lds[Q::TSL + t * 64 + lane] = ct[t];
-            if (lane < CP) lds[Q::VSL + NU * CP + lane] = cv;
+            if (lane < CP) lds[Q::VSL + lane] = cv;
         }
         wave_sync();
         SCHUR_STAMP(5);
@@ -519,51 +549,38 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
                 for (uint32_t r = 0; r < NU; ++r) rR[l * NU + r] = Rc[r];
             }
         }
-        // [W | A e] = A [Q^-1 | e],  [V | B f] = B [R^-1 | f]
-        T Xc[NX], Yc[NX];
+        // [W | A e] = A [Q^-1 | e],  [V | B f] = B [R^-1 | f],  T = W A' + V B': the left factors one column per lane in
+        // registers (A, B picked up from LDS once; W, V where they were computed), broadcast lane by lane inside the fma
+        T Ac[NX], Bc[NX], ar[NX], brow[NU];
+        {
+            const uint32_t lc = l < NX ? l : 0u, lb = l < NU ? l : 0u;
 #pragma unroll
-        for (uint32_t r = 0; r < NX; ++r) Xc[r] = Yc[r] = T(0);
+            for (uint32_t r = 0; r < NX; ++r) {
+                Ac[r] = rA[lc * NX + r];
+                Bc[r] = rB[lb * NX + r];
+                ar[r] = rA[r * NX + lc];            // row l of A
+            }
 #pragma unroll
-        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NX); ++q) {
-#pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) Xc[r] = fma_t(rA[q * NX + r], Qc[q], Xc[r]);
+            for (uint32_t q = 0; q < NU; ++q) brow[q] = rB[q * NX + lc];  // row l of B
         }
+        T Xc[NX], Yc[NX], Tc[NX];
 #pragma unroll
-        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NU); ++q) {
-#pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) Yc[r] = fma_t(rB[q * NX + r], Rc[q], Yc[r]);
-        }
-        T *wq = lds + Q::WSL + (qd + 1) * (NX + 1) * CP, *vq = lds + Q::VSL + (qd + 1) * (NU + 1) * CP, *tq = lds + Q::TSL + (qd + 1) * NX * CP;
+        for (uint32_t r = 0; r < NX; ++r) Xc[r] = Yc[r] = Tc[r] = T(0);
+        constexpr int PX = (GBDPCG_SCHUR_SKIP & 2) ? 1 : NX, PU = (GBDPCG_SCHUR_SKIP & 2) ? 1 : NU;
+        bcast_mac<0, PX, NX, NX>(Ac, Qc, Xc);
+        bcast_mac<0, PU, NX, NU>(Bc, Rc, Yc);
+        T *wq = lds + Q::WSL + (qd + 1) * (NX + 1) * CP, *vq = lds + Q::VSL + (qd + 1) * CP, *tq = lds + Q::TSL + (qd + 1) * NX * CP;
         if (l <= NX) {
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) wq[l * CP + r] = T(0) - Xc[r];
         }
-        if (l <= NU) {
+        if (l == NU) {
 #pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) vq[l * CP + r] = Yc[r];
+            for (uint32_t r = 0; r < NX; ++r) vq[r] = Yc[r];
         }
         SCHUR_STAMP(6);
-        // row l of A and of B
-        T ar[NX], brow[NU];
-#pragma unroll
-        for (uint32_t q = 0; q < NX; ++q) ar[q] = rA[q * NX + (l < NX ? l : 0)];
-#pragma unroll
-        for (uint32_t q = 0; q < NU; ++q) brow[q] = rB[q * NX + (l < NX ? l : 0)];
-        wave_sync();
-        // T = W A' + V B'
-        T Tc[NX];
-#pragma unroll
-        for (uint32_t r = 0; r < NX; ++r) Tc[r] = T(0);
-#pragma unroll
-        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NX); ++q) {
-#pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) Tc[r] = fma_t(-wq[q * CP + r], ar[q], Tc[r]);
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < ((GBDPCG_SCHUR_SKIP & 2) ? 1 : NU); ++q) {
-#pragma unroll
-            for (uint32_t r = 0; r < NX; ++r) Tc[r] = fma_t(vq[q * CP + r], brow[q], Tc[r]);
-        }
+        bcast_mac<0, PX, NX, NX>(Xc, ar, Tc);
+        bcast_mac<0, PU, NX, NU>(Yc, brow, Tc);
         if (l < NX) {
 #pragma unroll
             for (uint32_t r = 0; r < NX; ++r) tq[l * CP + r] = Tc[r];
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         wave_sync();
         SCHUR_STAMP(7);
         // D_j = T_{j-1} + Q_j^-1;  gamma_j = -(c_j + e_j - (A e + B f)_{j-1})
-        const T *tp = tq - NX * CP, *wp = wq - (NX + 1) * CP, *vp = vq - (NU + 1) * CP;
+        const T *tp = tq - NX * CP, *wp = wq - (NX + 1) * CP, *vp = vq - CP;
         {   // (reads first, then writes, as above)
             T tv[NX], cv[NX], wv[NX], vv[NX];
             const uint32_t lc = l < NX ? l : 0u;
@@ -580,7 +597,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
                 tv[r] = tp[lc * CP + r];
                 cv[r] = raw[Q::Rc + qd * NX + r];
                 wv[r] = wp[NX * CP + r];
-                vv[r] = vp[NU * CP + r];
+                vv[r] = vp[r];
             }
             if (l < NX) {
 #pragma unroll
