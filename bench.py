@@ -26,6 +26,8 @@ Printed JSON line (rank 0) also carries
   spmv         : the standalone block-tridiagonal SpMV (the kernel the >= 70 % HBM target is quoted on), timed
                  over 4 rotating matrices (1.23 GB > the 256 MiB Infinity Cache): an HBM statement
   configs      : driver-timed numbers for the other single-GPU BASELINE configs (C2, C4, C5's batch on one GPU)
+  mpc_step     : the steps either side of the solve at the headline batch shape: KKT blocks -> S, gamma
+                 (HBM-bound, with its fraction) -> Phi^-1 + converged PCG -> primal step (HBM-bound, with its fraction)
   cpu_baseline : the CPU oracle (oracle/pcg_oracle.c, a port -- the reference has no CPU path)
                  timed on this host's cores on a bounded sample of the same workload (N = 1 only)
 """
@@ -500,6 +502,7 @@ def run_rank(args, world, rank, local_rank):
 
     if world == 1 and not args.no_configs:
         out["configs"] = bench_configs(solver, torch, binding, synth, dev, stream)
+        out["mpc_step"] = bench_mpc_step(solver, torch, binding, synth, dev, stream)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, N, iters)
     if rank == 0:
@@ -577,6 +580,70 @@ def bench_configs(solver, torch, binding, synth, dev, stream):
         res[name] = rec
         del S, P, gamma, lam, r, p
         torch.cuda.empty_cache()
+    return res
+
+
+def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
+    """SURVEY 8f-4, the steps either side of the solve, at the headline batch shape (1024 problems, stateSize 14, controlSize 7,
+    knotPoints 128, fp32): KKT blocks -> S, gamma, G^-1 (gbdpcg_form_schur) -> stair Phi^-1 + PCG to 1e-6
+    (gbdpcg_form_pinv_solve) -> primal step (gbdpcg_recover_primal).  Each stage event-timed on the launch stream, median of
+    `reps`; the two new stages are one pass over their operands, so their bound is HBM: achieved = (every input once + every
+    output once) / time against the 8 TB/s spec.  The working set of a stage (0.3-0.75 GB) exceeds the 256 MiB Infinity Cache."""
+    nx, N, B = N_STATE, N_KNOTS, BATCH_PER_GPU
+    G, C, g, c = synth.kkt_torch(nx, nu, N, B, dev, torch.float32, seed=BASE_SEED)
+    S, gamma, Ginv = solver.form_schur(nx, nu, N, B, G, C, g, c, stream=stream)
+    Pinv, lam, z = torch.empty_like(S), torch.zeros_like(gamma), torch.empty_like(g)
+    r, p = torch.empty_like(gamma), torch.empty_like(gamma)
+    it = torch.zeros(B, dtype=torch.int32, device=dev)
+    fl = torch.zeros(B, dtype=torch.uint8, device=dev)
+    gr = solver.graph_form_pinv_solve(nx, N, B, S, Pinv, gamma, lam, r, p, 1e-6, 100, it, fl)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        torch.cuda.synchronize()
+        for e0, e1 in evs:
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+        torch.cuda.synchronize()
+        return median([a.elapsed_time(b) for a, b in evs]) * 1e3
+
+    def form():
+        solver.form_schur(nx, nu, N, B, G, C, g, c, S=S, gamma=gamma, Ginv=Ginv, stream=stream)
+
+    def solve():
+        lam.zero_()
+        gr.launch(stream)
+
+    def recover():
+        solver.recover_primal(nx, nu, N, B, Ginv, C, g, lam, z=z, stream=stream)
+
+    def chain():
+        form()
+        solve()
+        recover()
+
+    t_form, t_solve, t_rec, t_all = timed(form), timed(solve), timed(recover), timed(chain)
+    sym = bool(solver.check_symmetric(nx, N, B, S).all())
+    ok = int(fl.sum()) == 0 and bool(torch.isfinite(z).all())
+    by_form = (2 * G.numel() + C.numel() + g.numel() + c.numel() + S.numel() + gamma.numel()) * 4
+    by_rec = (Ginv.numel() + C.numel() + g.numel() + lam.numel() + z.numel()) * 4
+    res = {"shape": {"stateSize": nx, "controlSize": nu, "knotPoints": N, "batch": B, "dtype": "f32"},
+           "form_schur": {"kernel": "schur_form_quad_kernel<float,14,7>", "bound": "hbm", "us": t_form,
+                          "algorithmic_bytes": by_form, "achieved": by_form / t_form / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": by_form / t_form / 1e3 / HBM_PEAK_GBPS},
+           "form_pinv_solve": {"us": t_solve, "iters_mean": float(it.float().mean()), "tol": 1e-6,
+                               "note": "stair Phi^-1 formed from S + PCG to tolerance, one graph (the formation's symmetry "
+                                       "verdicts replace the solve's own test launch)"},
+           "recover_primal": {"kernel": "schur_recover_quad_kernel<float,14,7>", "bound": "hbm", "us": t_rec,
+                              "algorithmic_bytes": by_rec, "achieved": by_rec / t_rec / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": by_rec / t_rec / 1e3 / HBM_PEAK_GBPS},
+           "us_per_step_of_1024_problems": t_all, "kkt_systems_per_sec": B / (t_all * 1e-6),
+           "S_symmetric_in_storage": sym, "all_converged_and_finite": ok,
+           "statistic": f"median of {reps} event-timed repetitions per stage and of the three stages back to back"}
+    gr.close()
     return res
 
 

@@ -290,6 +290,14 @@ template <int J> __device__ __forceinline__ double row_bcast(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// acc += coef[q] * (v of lane q of the row), q = Q0 .. QN-1 in ascending order: a dot product whose vector sits one entry per lane.
+template <int Q0, int QN, int M, typename T> __device__ __forceinline__ void recover_dot(T &acc, const T (&coef)[M], T v)
+{
+    if constexpr (Q0 < QN) {
+        acc = fma_t(coef[Q0], row_bcast<Q0>(v), acc);
+        recover_dot<Q0 + 1, QN, M>(acc, coef, v);
+    }
+}
 // acc[r] += (src[r] of lane q of the row) * coef[q] for q in [Q0, QN): a block product whose left factor lives one column per
 // lane and whose right factor's column this lane holds in coef -- the broadcast rides on the fma as a DPP operand.
 // (v_fmac_*_dpp written out: hipcc pairs the fmas into v_pk_fma_f32, which takes no DPP operand, and keeps a v_mov_b32_dpp per
@@ -714,6 +722,80 @@ __global__ __launch_bounds__(256) void schur_recover_kernel(uint32_t nx, uint32_
         }
 }
 
+// ---- compile-time block sizes NX, NU <= 16: FOUR knots per wavefront, no LDS at all ----
+// The kernel above stages every block in LDS and walks it with runtime indices (two LDS reads per fma): 172 us for the 131072
+// rows of the BASELINE batch, 1.8 TB/s, on a step that moves 2.4 KB per row and has 0.5 flop per byte.  Here a 16-lane quarter
+// owns one row (problem, k) and every operand goes from memory straight into the registers of the lane that multiplies it:
+//   * lane l holds COLUMN l of A_k and B_k (14 contiguous elements each: (A' lambda+)_l and (B' lambda+)_l are dot products along
+//     a column) and ROW l of Q_k^-1 and R_k^-1 (element q of it comes with the quarter's q-th load: 14 lanes x 4 bytes, contiguous);
+//   * the vector a product multiplies sits one entry per lane (lambda_{k+1}; then t_x, t_u where they were computed) and reaches
+//     the fma as a DPP row broadcast -- no LDS, no shuffles through the crossbar;
+//   * every load of a row is requested before the first fma (53 registers of operands per lane), five or six waves per SIMD keep
+//     ~200 KB per compute unit in flight.
+// Same sums in the same order as the kernel above (q ascending, one fma chain per output entry): bit-identical results.
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(256) void schur_recover_quad_kernel(uint32_t N, uint64_t rows, const T *__restrict__ Ginv,
+                                                                const T *__restrict__ C, const T *__restrict__ g,
+                                                                const T *__restrict__ lambda, T *__restrict__ z)
+{
+    static_assert(NX <= 16 && NU <= NX, "one row per 16-lane quarter");
+    uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 15u;
+    const uint64_t row = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < rows;
+    const KktDims d(NX, NU, N);
+    const uint64_t prob = live ? row / N : 0;
+    const uint32_t k = live ? (uint32_t)(row - prob * N) : 0u;
+    const bool has_next = live && k + 1 < N;
+    const bool lx = live && l < NX, lu = has_next && l < NU;
+    const uint32_t cx = l < NX ? l : 0u, cu = l < NU ? l : 0u;   // clamped: idle lanes read what a live lane reads
+    const T *Gi = Ginv + prob * d.szG + (size_t)k * d.sg, *Ck = C + prob * d.szC + (size_t)k * d.sc;
+    const T *gk = g + prob * d.szg + (size_t)k * d.sv;
+    const T *lk = lambda + (prob * N + k) * NX;
+
+    T a[NX], b[NX], qi[NX], ri[NU];
+    T lam_n = T(0), tx = T(0), tu = T(0);
+    if (live) {
+        tx = gk[cx] + lk[cx];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) qi[q] = Gi[q * NX + cx];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) qi[q] = T(0);
+    }
+    if (has_next) {
+        lam_n = lk[NX + cx];
+        tu = gk[NX + cu];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            a[q] = Ck[cx * NX + q];
+            b[q] = Ck[NX * NX + cu * NX + q];
+        }
+#pragma unroll
+        for (int q = 0; q < NU; ++q) ri[q] = Gi[NX * NX + q * NU + cu];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) a[q] = b[q] = T(0);
+#pragma unroll
+        for (int q = 0; q < NU; ++q) ri[q] = T(0);
+    }
+    // t_x = q_k + lambda_k - A_k' lambda_{k+1},  t_u = r_k - B_k' lambda_{k+1}   (the rows of the last knot have neither product)
+    T sa = T(0), sb = T(0);
+    recover_dot<0, NX>(sa, a, lam_n);
+    recover_dot<0, NX>(sb, b, lam_n);
+    if (has_next) {
+        tx -= sa;
+        tu -= sb;
+    }
+    // x_k = -Q_k^-1 t_x,  u_k = -R_k^-1 t_u
+    T sx = T(0), su = T(0);
+    recover_dot<0, NX>(sx, qi, tx);
+    recover_dot<0, NU>(su, ri, tu);
+    T *zk = z + prob * d.szg + (size_t)k * d.sv;
+    if (lx) zk[l] = -sx;
+    if (lu) zk[NX + l] = -su;
+}
+
 // Waves per workgroup for a per-wave LDS need; 0 = does not fit one CU.
 static uint32_t waves_for(const DeviceInfo &dev, size_t wave_bytes)
 {
@@ -765,10 +847,18 @@ template <typename T>
 hipError_t launch_recover_primal(const DeviceInfo &dev, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *Ginv,
                                  const T *C, const T *g, const T *lambda, T *z, hipStream_t s)
 {
+    const uint64_t rows = (uint64_t)batch * N;
+    // GBDPCG_SCHUR_GENERAL=1: the any-size kernel also where the four-rows-per-wave form exists (A/B runs, tests)
+    const char *env = getenv("GBDPCG_SCHUR_GENERAL");
+    if (nx == 14 && nu == 7 && !(env && env[0] == '1')) {
+        const uint64_t grid = (rows + 15) / 16;   // 4 waves x 4 rows per workgroup
+        if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((schur_recover_quad_kernel<T, 14, 7>), dim3((uint32_t)grid), dim3(256), 0, s, N, rows, Ginv, C, g, lambda, z);
+        return hipGetLastError();
+    }
     const size_t wave_bytes = (size_t)recover_wave_elems(nx, nu) * sizeof(T);
     const uint32_t waves = waves_for(dev, wave_bytes);
     if (!waves) return hipErrorInvalidValue;
-    const uint64_t rows = (uint64_t)batch * N;
     const uint64_t grid = (rows + waves - 1) / waves;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = waves * wave_bytes;

@@ -259,3 +259,31 @@ def gen_torch(n: int, N: int, batch: int, device, dtype, seed: int = 1234, a: fl
         P[lo:lo + b] = pack(*stair_pinv_blocks(L, D, R, xp=torch)).to(dtype)
         gamma[lo:lo + b] = gam.to(dtype)
     return dict(n=n, N=N, batch=batch, S=S, Pinv=P, gamma=gamma)
+
+
+def kkt_torch(nx: int, nu: int, N: int, batch: int, device, dtype, seed: int = 0):
+    """Synthetic KKT blocks of `batch` linearised MPC problems in the packed layouts gbdpcg_form_schur_* takes
+    (include/gbdpcg.h), drawn on the device: cost blocks M M' + I (symmetric positive definite), dynamics
+    A = I + noise, B, gradients and constraint residuals normal.  Returns flat G, C, g, c.  Measurement input (bench.py,
+    tools/schur_run.py); the parity tests draw theirs with oracle/schur_oracle.gen."""
+    import torch
+    gen = torch.Generator(device=device).manual_seed(seed)
+    sg, sc, sv = nx * nx + nu * nu, nx * nx + nx * nu, nx + nu
+
+    def spd(m, count):
+        a = torch.randn(count, m, m, device=device, dtype=dtype, generator=gen) / m ** 0.5
+        return a @ a.transpose(1, 2) + torch.eye(m, device=device, dtype=dtype)
+
+    G = torch.zeros(batch, N, sg, device=device, dtype=dtype)
+    G[:, :, :nx * nx] = spd(nx, batch * N).reshape(batch, N, -1)
+    G[:, :, nx * nx:] = spd(nu, batch * N).reshape(batch, N, -1)
+    G = G.reshape(batch, -1)[:, :sg * N - nu * nu].contiguous()
+    C = torch.zeros(batch, max(N - 1, 0), sc, device=device, dtype=dtype)
+    if N > 1:
+        A = torch.eye(nx, device=device, dtype=dtype) + 0.3 * torch.randn(batch * (N - 1), nx, nx, device=device, dtype=dtype,
+                                                                         generator=gen) / nx ** 0.5
+        C[:, :, :nx * nx] = A.transpose(1, 2).reshape(batch, N - 1, -1)
+        C[:, :, nx * nx:] = torch.randn(batch, N - 1, nx * nu, device=device, dtype=dtype, generator=gen) / nx ** 0.5
+    g = torch.randn(batch, sv * N - nu, device=device, dtype=dtype, generator=gen)
+    c = 0.1 * torch.randn(batch, nx * N, device=device, dtype=dtype, generator=gen)
+    return G.reshape(-1), C.reshape(-1), g.reshape(-1), c.reshape(-1)

@@ -11,28 +11,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from gbd_pcg_amd import binding  # noqa: E402
+from gbd_pcg_amd import binding, synth  # noqa: E402
 
 
 def kkt_on_device(nx, nu, N, B, dtype, seed=0):
-    gen = torch.Generator(device="cuda").manual_seed(seed)
-    sg, sc, sv = nx * nx + nu * nu, nx * nx + nx * nu, nx + nu
-
-    def spd(m, count):
-        a = torch.randn(count, m, m, device="cuda", dtype=dtype, generator=gen) / m ** 0.5
-        return a @ a.transpose(1, 2) + torch.eye(m, device="cuda", dtype=dtype)
-
-    G = torch.zeros(B, N, sg, device="cuda", dtype=dtype)
-    G[:, :, :nx * nx] = spd(nx, B * N).reshape(B, N, -1)
-    G[:, :, nx * nx:] = spd(nu, B * N).reshape(B, N, -1)
-    G = G.reshape(B, -1)[:, :sg * N - nu * nu].contiguous()
-    C = torch.zeros(B, N - 1, sc, device="cuda", dtype=dtype)
-    A = torch.eye(nx, device="cuda", dtype=dtype) + 0.3 * torch.randn(B * (N - 1), nx, nx, device="cuda", dtype=dtype, generator=gen) / nx ** 0.5
-    C[:, :, :nx * nx] = A.transpose(1, 2).reshape(B, N - 1, -1)
-    C[:, :, nx * nx:] = (torch.randn(B, N - 1, nx * nu, device="cuda", dtype=dtype, generator=gen) / nx ** 0.5)
-    g = torch.randn(B, sv * N - nu, device="cuda", dtype=dtype, generator=gen)
-    c = 0.1 * torch.randn(B, nx * N, device="cuda", dtype=dtype, generator=gen)
-    return G.reshape(-1), C.reshape(-1), g.reshape(-1), c.reshape(-1)
+    return synth.kkt_torch(nx, nu, N, B, "cuda", dtype, seed)
 
 
 def timed(fn, reps):

@@ -90,6 +90,30 @@ def test_four_knot_form_runs_of_every_length(solver, N, B):
         test_form_schur_and_recover_vs_oracle(solver, 14, 7, N, B, dtype, tol)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N,B", [(1, 1), (3, 1), (37, 3), (128, 5), (5, 13)])
+def test_register_recover_kernel_is_bit_identical_with_the_general_one(solver, monkeypatch, N, B, dtype):
+    """nx 14, nu 7 takes schur_recover_quad_kernel (four rows per wavefront, operands straight into registers): the same fma
+    chains in the same order as the LDS kernel, so the two must agree bit for bit -- also on row counts that leave quarters,
+    waves and workgroups partly empty (the last knot of a problem has no A, B, R^-1, r: what follows it in memory is the next
+    problem's data, which the oracle comparison would expose)."""
+    nx, nu = 14, 7
+    d = so.gen(nx, nu, N, seed=50 + N, batch=B, dtype=dtype)
+    rng = np.random.default_rng(2)
+    lam = rng.standard_normal(B * nx * N).astype(dtype)
+    _, _, Gi = zip(*(so.form_schur(nx, nu, N, d["G"][b], d["C"][b], d["g"][b], d["c"][b]) for b in range(B)))
+    dGi = dev(np.concatenate(Gi).astype(dtype))
+    dC, dg, dl = dev(d["C"].reshape(-1)), dev(d["g"].reshape(-1)), dev(lam)
+    zq = solver.recover_primal(nx, nu, N, B, dGi, dC, dg, dl)
+    monkeypatch.setenv("GBDPCG_SCHUR_GENERAL", "1")
+    zg = solver.recover_primal(nx, nu, N, B, dGi, dC, dg, dl)
+    monkeypatch.delenv("GBDPCG_SCHUR_GENERAL")
+    torch.cuda.synchronize()
+    assert torch.equal(zq, zg) and bool(torch.isfinite(zq).all())
+    zo = np.concatenate([so.recover_primal(nx, nu, N, d["G"][b], d["C"][b], d["g"][b], lam.reshape(B, -1)[b]) for b in range(B)])
+    assert close(zq.cpu().numpy(), zo, 2e-3 if dtype == np.float32 else 1e-10)
+
+
 def test_form_schur_without_ginv_and_bad_arguments(solver):
     nx, nu, N, B = 14, 7, 8, 2
     d = so.gen(nx, nu, N, seed=3, batch=B, dtype=np.float32)
