@@ -32,7 +32,7 @@
 #define GBDPCG_SCHUR_SKIP 0   // timing builds only: 1 no elimination, 2 no products, 4 no stores, 8 no requests after the first (results are wrong)
 #endif
 
-#ifdef GBDPCG_SCHUR_STAMPS   // timing builds only: s_memtime at the phase boundaries of one step of workgroup 0, left in the tail of gamma
+#ifdef GBDPCG_SCHUR_STAMPS   // timing builds only: s_memtime at the phase boundaries of one step of workgroup 0, left BEHIND gamma (tools/schur_run.py --stamps allocates 96 bytes more)
 #define SCHUR_STAMP(i) do { if (stamp_now) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st[i] = t_; } } while (0)
 #else
 #define SCHUR_STAMP(i) do { } while (0)
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void schur_form_kernel(uint32_t nx, uint32_t n
     }
 }
 
-// ---- compile-time block sizes NX, NU <= 15 and knotPoints a multiple of 4: FOUR knots per wavefront, registers instead of LDS ----
+// ---- compile-time block sizes NX, NU <= 15: FOUR knots per wavefront, registers instead of LDS ----
 // The kernel above pays two LDS reads per fma and a pair of wave syncs per pivot step of a tableau it walks with runtime
 // indices: 1.44 ms for the 131072 rows of the BASELINE batch (1024 x 128, nx 14, nu 7), 0.5 TB/s.  Here a wavefront WALKS along
 // a run of consecutive knots of one problem, four at a time, one knot per 16-lane quarter:
@@ -443,9 +443,10 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #pragma unroll
         for (uint32_t o = 0; o < 4 * Q::SV * DW; o += 64)
             if (o + lane < 4 * Q::SV * DW && o + lane < lim_g) dma_dword(sg, (o + lane) * 4, base + (Q::Rg * DW + o) * 4);
+        const uint32_t lim_c = (uint32_t)(d.szc - (size_t)jb * NX) * DW;
 #pragma unroll
         for (uint32_t o = 0; o < 4 * NX * DW; o += 64)
-            if (o + lane < 4 * NX * DW) dma_dword(sc, (o + lane) * 4, base + (Q::Rc * DW + o) * 4);
+            if (o + lane < 4 * NX * DW && o + lane < lim_c) dma_dword(sc, (o + lane) * 4, base + (Q::Rc * DW + o) * 4);
     };
 
     const bool pre = j_start != 0;                     // one silent step on the four knots before the run
@@ -481,11 +482,20 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         SCHUR_STAMP(2);
         T *raw = lds + b * Q::RAW_P;
         T *rQ = raw + Q::RG + qd * Q::SG, *rR = rQ + NX * NX, *rA = raw + Q::RC + qd * Q::SC, *rB = rA + NX * NX;
-        if (jb + 4 == N) {  // the last knot has no R, A, B, r in memory: R = I, the rest 0 (W = V = 0: R_{N-1} = 0)
-            T *lR = raw + Q::RG + 3 * Q::SG + NX * NX, *lA = raw + Q::RC + 3 * Q::SC, *lr = raw + Q::Rg + 3 * Q::SV + NX;
+        if (jb + 4 >= N) {  // the last knot has no R, A, B, r in memory: R = I, the rest 0 (W = V = 0: R_{N-1} = 0)
+            const uint32_t ql = N - 1 - jb;   // its quarter; knotPoints % 4 != 0 leaves quarters behind it that own no knot
+            T *lR = raw + Q::RG + ql * Q::SG + NX * NX, *lA = raw + Q::RC + ql * Q::SC, *lr = raw + Q::Rg + ql * Q::SV + NX;
             for (uint32_t i = lane; i < NU * NU; i += 64) lR[i] = (i / NU == i % NU) ? T(1) : T(0);
             for (uint32_t i = lane; i < Q::SC; i += 64) lA[i] = T(0);
             if (lane < NU) lr[lane] = T(0);
+            // quarters without a knot eliminate the identity (what their buffers hold is stale or the next problem's; nothing
+            // they compute is stored or read by a quarter that owns a knot)
+            for (uint32_t q = ql + 1; q < 4; ++q) {
+                T *dQ = raw + Q::RG + q * Q::SG, *dR = dQ + NX * NX, *dA = raw + Q::RC + q * Q::SC;
+                for (uint32_t i = lane; i < NX * NX; i += 64) dQ[i] = (i / NX == i % NX) ? T(1) : T(0);
+                for (uint32_t i = lane; i < NU * NU; i += 64) dR[i] = (i / NU == i % NU) ? T(1) : T(0);
+                for (uint32_t i = lane; i < Q::SC; i += 64) dA[i] = T(0);
+            }
         }
         wave_sync();
         // this lane's columns: Q_j (lane NX: q_j), R_j (lane NU: r_j)
@@ -647,17 +657,18 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         }
 #endif
     }
-    // S and gamma of the last step
+    // S and gamma of the last step (the last step of a problem whose knotPoints are not a multiple of 4 holds fewer than 4 rows)
     if (pending) {
+        const uint32_t live = j_end == N && (N & 3u) ? (N & 3u) : 4u;
 #pragma unroll
         for (uint32_t t = 0; t < Q::OUT_T; ++t)
-            if (t * 64 + lane < 4 * Q::SROW) So_prev[t * 64 + lane] = lds[src[t]];
-        if (lane < 4 * NX) gam_prev[lane] = lds[Q::GAM + lane];
+            if (t * 64 + lane < live * Q::SROW) So_prev[t * 64 + lane] = lds[src[t]];
+        if (lane < live * NX) gam_prev[lane] = lds[Q::GAM + lane];
     }
 #ifdef GBDPCG_SCHUR_STAMPS
     if (blockIdx.x == 0 && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long *out = reinterpret_cast<unsigned long long *>(gamma + (size_t)(waves / rpp) * N * NX) - 12;
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(gamma + (size_t)(waves / rpp) * N * NX);  // 96 bytes past the end: the tool allocates them
         for (int i = 0; i < 12; ++i) out[i] = st[i];
     }
 #endif
@@ -811,9 +822,10 @@ hipError_t launch_form_schur(const DeviceInfo &dev, uint32_t nx, uint32_t nu, ui
 {
     // GBDPCG_SCHUR_GENERAL=1: the any-size kernel also where the four-knots-per-wave form exists (A/B runs, tests)
     const char *env = getenv("GBDPCG_SCHUR_GENERAL");
-    if (nx == 14 && nu == 7 && N % 4 == 0 && !(env && env[0] == '1')) {
+    if (nx == 14 && nu == 7 && !(env && env[0] == '1')) {
         using Q = QuadGeom<T, 14, 7>;
         // one run per problem when the batch alone fills the device, shorter runs (each pays one silent step) otherwise
+        // (runs are multiples of 4 knots that divide knotPoints: other horizons are one run, the last step partly empty)
         uint32_t run = N;
         while (run % 8 == 0 && (uint64_t)batch * (N / run) < 4ull * dev.num_cus) run /= 2;
         const uint64_t nwaves = (uint64_t)batch * (N / run);

@@ -68,8 +68,7 @@ def test_form_schur_blocks_wider_than_a_wavefront(solver):
 
 
 def test_general_kernel_where_the_four_knot_form_exists(solver, monkeypatch):
-    """nx 14, nu 7, knotPoints % 4 == 0 normally takes schur_form_quad_kernel; GBDPCG_SCHUR_GENERAL=1 keeps the any-size kernel on
-    those shapes too.  Both against the oracle, and against each other to rounding."""
+    """nx 14, nu 7 normally takes schur_form_quad_kernel; GBDPCG_SCHUR_GENERAL=1 keeps the any-size kernel on those shapes too.  Both against the oracle, and against each other to rounding."""
     nx, nu, N, B = 14, 7, 32, 5
     d = so.gen(nx, nu, N, seed=8, batch=B, dtype=np.float32)
     dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
@@ -82,10 +81,23 @@ def test_general_kernel_where_the_four_knot_form_exists(solver, monkeypatch):
         assert close(a, b, 1e-4) and not np.array_equal(a, b)   # two kernels: other summation order, no mirrored inverses
 
 
-@pytest.mark.parametrize("N,B", [(4, 1), (8, 3), (128, 2), (64, 40), (36, 7), (256, 1)])
+@pytest.mark.parametrize("N,B", [(4, 1), (8, 3), (128, 2), (64, 40), (36, 7), (256, 1), (1, 3), (2, 2), (3, 5), (5, 3), (50, 3), (127, 2),
+                                 (6, 300)])
 def test_four_knot_form_runs_of_every_length(solver, N, B):
     """The walking kernel splits a problem into runs when the batch alone does not fill the device (each run starts with a silent
-    step on the four knots before it): one problem of 256 knots is 64 runs of 4, 40 problems of 64 knots 2 runs each, ..."""
+    step on the four knots before it): one problem of 256 knots is 64 runs of 4, 40 problems of 64 knots 2 runs each, ...
+    Horizons that are not a multiple of 4 are one run whose last step has quarters without a knot (nothing of theirs may be
+    stored: the arrays end with the last knot -- and the outputs behind them are checked for stray writes)."""
+    if N % 4:
+        nx, nu = 14, 7
+        d = so.gen(nx, nu, N, seed=7, batch=B, dtype=np.float32)
+        dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
+        nS, ng, nG = B * 3 * nx * nx * N, B * nx * N, dG.numel()
+        big = [torch.full((m + 4096,), 777.0, dtype=torch.float32, device="cuda") for m in (nS, ng, nG)]
+        solver.form_schur(nx, nu, N, B, dG, dC, dg, dc, S=big[0], gamma=big[1], Ginv=big[2])
+        torch.cuda.synchronize()
+        for t, m in zip(big, (nS, ng, nG)):
+            assert bool((t[m:] == 777.0).all()) and bool(torch.isfinite(t[:m]).all())
     for dtype, tol in ((np.float32, 2e-4), (np.float64, 1e-11)):
         test_form_schur_and_recover_vs_oracle(solver, 14, 7, N, B, dtype, tol)
 
