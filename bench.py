@@ -597,6 +597,7 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
     it = torch.zeros(B, dtype=torch.int32, device=dev)
     fl = torch.zeros(B, dtype=torch.uint8, device=dev)
     gr = solver.graph_form_pinv_solve(nx, N, B, S, Pinv, gamma, lam, r, p, 1e-6, 100, it, fl)
+    gr_all = solver.graph_kkt_step(nx, nu, N, B, G, C, g, c, S, gamma, Ginv, Pinv, lam, r, p, 1e-6, 100, it, fl, z)
 
     def timed(fn):
         for _ in range(3):
@@ -620,10 +621,9 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
     def recover():
         solver.recover_primal(nx, nu, N, B, Ginv, C, g, lam, z=z, stream=stream)
 
-    def chain():
-        form()
-        solve()
-        recover()
+    def chain():            # the whole step as one graph (gbdpcg_graph_create_kkt_step)
+        lam.zero_()
+        gr_all.launch(stream)
 
     t_form, t_solve, t_rec, t_all = timed(form), timed(solve), timed(recover), timed(chain)
     sym = bool(solver.check_symmetric(nx, N, B, S).all())
@@ -642,8 +642,10 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
                               "frac": by_rec / t_rec / 1e3 / HBM_PEAK_GBPS},
            "us_per_step_of_1024_problems": t_all, "kkt_systems_per_sec": B / (t_all * 1e-6),
            "S_symmetric_in_storage": sym, "all_converged_and_finite": ok,
-           "statistic": f"median of {reps} event-timed repetitions per stage and of the three stages back to back"}
+           "statistic": f"median of {reps} event-timed repetitions per stage, and of the whole step replayed as one hipGraph "
+                        "(gbdpcg_graph_create_kkt_step, lambda reset to 0 before each replay)"}
     gr.close()
+    gr_all.close()
     return res
 
 

@@ -32,6 +32,7 @@ SYMBOLS = [
     "gbdpcg_form_pinv_solve_f32", "gbdpcg_form_pinv_solve_f64",
     "gbdpcg_graph_create_form_pinv_solve_f32", "gbdpcg_graph_create_form_pinv_solve_f64",
     "gbdpcg_form_schur_f32", "gbdpcg_form_schur_f64", "gbdpcg_recover_primal_f32", "gbdpcg_recover_primal_f64",
+    "gbdpcg_kkt_step_f32", "gbdpcg_kkt_step_f64", "gbdpcg_graph_create_kkt_step_f32", "gbdpcg_graph_create_kkt_step_f64",
     "gbdpcg_csr_to_bt_f32", "gbdpcg_csr_to_bt_f64", "gbdpcg_version",
 ]
 
@@ -277,6 +278,37 @@ class Solver:
         self._check(fn(self.h, ctypes.c_uint32(nx), ctypes.c_uint32(nu), ctypes.c_uint32(N), ctypes.c_uint32(batch), _p(Ginv),
                        _p(C), _p(g), _p(lam), _p(z), self._stream(stream)), "recover_primal")
         return z
+
+
+    def _kkt_args(self, nx, nu, N, batch, G, C, g, c, S, gamma, Ginv, Pinv, kind, lam, r, p, tol, max_iter, iters, mie, z):
+        suf, ft = _suffix(G)
+        return suf, (self.h, ctypes.c_uint32(nx), ctypes.c_uint32(nu), ctypes.c_uint32(N), ctypes.c_uint32(batch), _p(G), _p(C),
+                     _p(g), _p(c), _p(S), _p(gamma), _p(Ginv), _p(Pinv), ctypes.c_int(kind), _p(lam), _p(r), _p(p), ft(tol),
+                     ctypes.c_uint32(max_iter), _p(iters), _p(mie), _p(z))
+
+    def kkt_step(self, nx, nu, N, batch, G, C, g, c, S, gamma, Ginv, Pinv, lam, z, kind=PINV_STAIR, r=None, p=None, tol=1e-6,
+                 max_iter=25, iters=None, max_iter_exit=None, stream=None):
+        """gbdpcg_kkt_step_*: KKT blocks -> S, gamma, G^-1 -> Pinv -> PCG (warm start from lam) -> primal step z, one call."""
+        import torch
+        if iters is None:
+            iters = torch.zeros(batch, dtype=torch.int32, device=G.device)
+        if max_iter_exit is None:
+            max_iter_exit = torch.zeros(batch, dtype=torch.uint8, device=G.device)
+        suf, args = self._kkt_args(nx, nu, N, batch, G, C, g, c, S, gamma, Ginv, Pinv, kind, lam, r, p, tol, max_iter, iters,
+                                   max_iter_exit, z)
+        fn = getattr(self.lib, f"gbdpcg_kkt_step_{suf}")
+        self._check(fn(*args, self._stream(stream)), "kkt_step")
+        return iters, max_iter_exit
+
+    def graph_kkt_step(self, nx, nu, N, batch, G, C, g, c, S, gamma, Ginv, Pinv, lam, r, p, tol, max_iter, iters, max_iter_exit, z,
+                       kind=PINV_STAIR):
+        """Capture the whole step into one hipGraph (gbdpcg_graph_create_kkt_step_*)."""
+        suf, args = self._kkt_args(nx, nu, N, batch, G, C, g, c, S, gamma, Ginv, Pinv, kind, lam, r, p, tol, max_iter, iters,
+                                   max_iter_exit, z)
+        gr = ctypes.c_void_p()
+        fn = getattr(self.lib, f"gbdpcg_graph_create_kkt_step_{suf}")
+        self._check(fn(*args, ctypes.byref(gr)), "graph_create_kkt_step")
+        return Graph(self, gr, keep=(G, C, g, c, S, gamma, Ginv, Pinv, lam, r, p, iters, max_iter_exit, z))
 
 
 class Graph:

@@ -442,10 +442,41 @@ gbdpcg_status solve_host_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, const T
 }
 
 template <typename T>
+gbdpcg_status form_schur_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *d_G, const T *d_C,
+                              const T *d_g, const T *d_c, T *d_S, T *d_gamma, T *d_Ginv, void *stream);
+template <typename T>
+gbdpcg_status recover_primal_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *d_Ginv,
+                                  const T *d_C, const T *d_g, const T *d_lambda, T *d_z, void *stream);
+
+// The operands of the steps either side of the solve (gbdpcg_kkt_step_*): S and gamma are formed from them before, z after.
+template <typename T> struct KktOperands {
+    uint32_t nu;
+    const T *G, *C, *g, *c;
+    T *Ginv, *z;
+};
+
+// KKT blocks -> S, gamma, G^-1 -> Phi^-1 -> PCG -> primal step, on one stream (capturable: no allocation after the first
+// call of a shape, no synchronisation).
+template <typename T>
+gbdpcg_status kkt_step_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t N, uint32_t batch, const KktOperands<T> &k, T *d_S, T *d_gamma,
+                            T *d_Pinv, gbdpcg_pinv_kind kind, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
+                            uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream)
+{
+    if (!k.Ginv || !k.z) return GBDPCG_ERR_INVALID;
+    gbdpcg_status st = form_schur_impl<T>(h, nx, k.nu, N, batch, k.G, k.C, k.g, k.c, d_S, d_gamma, k.Ginv, stream);
+    if (st != GBDPCG_OK) return st;
+    st = form_pinv_solve_impl<T>(h, nx, N, batch, d_S, d_Pinv, kind, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit,
+                                 stream);
+    if (st != GBDPCG_OK) return st;
+    return recover_primal_impl<T>(h, nx, k.nu, N, batch, k.Ginv, k.C, k.g, d_lambda, k.z, stream);
+}
+
+template <typename T>
 gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S,
                                 const T *d_Pinv, const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol,
                                 uint32_t max_iter, uint32_t *d_iters, uint8_t *d_exit, gbdpcg_graph_t *out,
-                                int form_kind = -1)  // >= 0: the graph also forms Pinv (written through d_Pinv) from S
+                                int form_kind = -1,  // >= 0: the graph also forms Pinv (written through d_Pinv) from S
+                                const KktOperands<T> *kkt = nullptr)  // the graph also forms S, gamma (written through d_S, d_gamma) and recovers z
 {
     if (!h || !out) return GBDPCG_ERR_INVALID;
     *out = nullptr;
@@ -473,7 +504,10 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     gbdpcg_status st = GBDPCG_OK;
     if (e == hipSuccess) {
-        if (form_kind >= 0)
+        if (kkt)
+            st = kkt_step_impl<T>(h, n, N, batch, *kkt, const_cast<T *>(d_S), const_cast<T *>(d_gamma), const_cast<T *>(d_Pinv),
+                                  (gbdpcg_pinv_kind)form_kind, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit, cs);
+        else if (form_kind >= 0)
             st = form_pinv_solve_impl<T>(h, n, N, batch, d_S, const_cast<T *>(d_Pinv), (gbdpcg_pinv_kind)form_kind, d_gamma,
                                          d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit, cs);
         else
@@ -911,6 +945,31 @@ gbdpcg_status gbdpcg_graph_create_form_pinv_solve_f64(gbdpcg_handle_t h, uint32_
     return graph_create_impl<double>(h, n, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters,
                                      d_max_iter_exit, out, (int)kind);
 }
+
+#define GBDPCG_KKT_STEP(SUF, TYPE)                                                                                                  \
+    gbdpcg_status gbdpcg_kkt_step_##SUF(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const TYPE *d_G,     \
+                                        const TYPE *d_C, const TYPE *d_g, const TYPE *d_c, TYPE *d_S, TYPE *d_gamma, TYPE *d_Ginv,     \
+                                        TYPE *d_Pinv, gbdpcg_pinv_kind kind, TYPE *d_lambda, TYPE *d_r, TYPE *d_p, TYPE tol,           \
+                                        uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit, TYPE *d_z, void *stream)       \
+    {                                                                                                                               \
+        const KktOperands<TYPE> k{nu, d_G, d_C, d_g, d_c, d_Ginv, d_z};                                                             \
+        return kkt_step_impl<TYPE>(h, nx, N, batch, k, d_S, d_gamma, d_Pinv, kind, d_lambda, d_r, d_p, tol, max_iter, d_iters,       \
+                                   d_max_iter_exit, (hipStream_t)stream);                                                           \
+    }                                                                                                                               \
+    gbdpcg_status gbdpcg_graph_create_kkt_step_##SUF(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,         \
+                                                     const TYPE *d_G, const TYPE *d_C, const TYPE *d_g, const TYPE *d_c, TYPE *d_S,    \
+                                                     TYPE *d_gamma, TYPE *d_Ginv, TYPE *d_Pinv, gbdpcg_pinv_kind kind,                \
+                                                     TYPE *d_lambda, TYPE *d_r, TYPE *d_p, TYPE tol, uint32_t max_iter,               \
+                                                     uint32_t *d_iters, uint8_t *d_max_iter_exit, TYPE *d_z, gbdpcg_graph_t *out)     \
+    {                                                                                                                               \
+        if (!d_S || !d_gamma || !d_Pinv || !d_Ginv || !d_z || (int)kind < 0 || (int)kind > 2) return GBDPCG_ERR_INVALID;           \
+        const KktOperands<TYPE> k{nu, d_G, d_C, d_g, d_c, d_Ginv, d_z};                                                             \
+        return graph_create_impl<TYPE>(h, nx, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters,            \
+                                       d_max_iter_exit, out, (int)kind, &k);                                                        \
+    }
+GBDPCG_KKT_STEP(f32, float)
+GBDPCG_KKT_STEP(f64, double)
+#undef GBDPCG_KKT_STEP
 
 gbdpcg_status gbdpcg_csr_to_bt_f32(uint32_t n, uint32_t N, const uint32_t *row_ptr, const uint32_t *col_ind,
                                    const float *val, float *h_M)

@@ -313,6 +313,34 @@ gbdpcg_status gbdpcg_recover_primal_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t
                                         const double *d_Ginv, const double *d_C, const double *d_g,
                                         const double *d_lambda, double *d_z, void *stream);
 
+/* One inner step of the SQP loop as ONE call (or one hipGraph for fixed buffers): gbdpcg_form_schur_* writes S, gamma and
+ * G^-1, gbdpcg_form_pinv_solve_* forms Phi^-1 from that S (the S of form_schur is symmetric in storage, so in the default
+ * symmetric mode the solve runs its resident symmetric kernels without a test launch of its own) and iterates from the
+ * d_lambda it finds (warm start), gbdpcg_recover_primal_* writes the primal step z.  Same results as the three calls.
+ * Every buffer is the caller's (layouts above); d_r, d_p may be NULL as in gbdpcg_solve_*.  Replay the graph after
+ * rewriting G, C, g, c (and lambda, if no warm start is wanted) in place. */
+gbdpcg_status gbdpcg_kkt_step_f32(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const float *d_G,
+                                  const float *d_C, const float *d_g, const float *d_c, float *d_S, float *d_gamma,
+                                  float *d_Ginv, float *d_Pinv, gbdpcg_pinv_kind kind, float *d_lambda, float *d_r, float *d_p,
+                                  float tol, uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit, float *d_z,
+                                  void *stream);
+gbdpcg_status gbdpcg_kkt_step_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const double *d_G,
+                                  const double *d_C, const double *d_g, const double *d_c, double *d_S, double *d_gamma,
+                                  double *d_Ginv, double *d_Pinv, gbdpcg_pinv_kind kind, double *d_lambda, double *d_r,
+                                  double *d_p, double tol, uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit,
+                                  double *d_z, void *stream);
+gbdpcg_status gbdpcg_graph_create_kkt_step_f32(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                               const float *d_G, const float *d_C, const float *d_g, const float *d_c,
+                                               float *d_S, float *d_gamma, float *d_Ginv, float *d_Pinv, gbdpcg_pinv_kind kind,
+                                               float *d_lambda, float *d_r, float *d_p, float tol, uint32_t max_iter,
+                                               uint32_t *d_iters, uint8_t *d_max_iter_exit, float *d_z, gbdpcg_graph_t *out);
+gbdpcg_status gbdpcg_graph_create_kkt_step_f64(gbdpcg_handle_t h, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch,
+                                               const double *d_G, const double *d_C, const double *d_g, const double *d_c,
+                                               double *d_S, double *d_gamma, double *d_Ginv, double *d_Pinv,
+                                               gbdpcg_pinv_kind kind, double *d_lambda, double *d_r, double *d_p, double tol,
+                                               uint32_t max_iter, uint32_t *d_iters, uint8_t *d_max_iter_exit, double *d_z,
+                                               gbdpcg_graph_t *out);
+
 /* CSR ingestion (f3): repacks a host CSR matrix (csr_t<T>, include/types.cuh:7-15) whose
  * sparsity lies inside the block-tridiagonal pattern into the [L|D|R] layout (host arrays).
  * Entries outside the pattern give GBDPCG_ERR_INVALID.  Implements what the stub overload

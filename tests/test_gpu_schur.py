@@ -186,3 +186,55 @@ def test_form_schur_full_config3_batch(solver):
         assert np.array_equal(Sh[b], Sh[b % 8])   # S depends on G and C only
         oS, og, _ = so.form_schur(nx, nu, N, arr["G"][b], arr["C"][b], arr["g"][b], arr["c"][b])
         assert close(Sh[b], oS, 2e-4) and close(gh[b], og, 2e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kkt_step_is_the_three_calls(solver, dtype):
+    """gbdpcg_kkt_step_* and its graph form against form_schur + form_pinv_solve + recover_primal issued one by one: the same
+    kernels on the same buffers, so every output must agree bit for bit -- cold start, a replay after the inputs were rewritten in
+    place, and a replay that starts from the previous lambda (warm start: no more iterations than the cold one)."""
+    nx, nu, N, B = 14, 7, 24, 9
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    d = so.gen(nx, nu, N, seed=31, batch=B, dtype=dtype)
+    d2 = so.gen(nx, nu, N, seed=32, batch=B, dtype=dtype)
+    G, C, g, c = (dev(d[k].reshape(-1)) for k in "GCgc")
+
+    def by_hand():
+        S, gamma, Ginv = solver.form_schur(nx, nu, N, B, G, C, g, c)
+        Pinv, lam = torch.empty_like(S), torch.zeros_like(gamma)
+        it, fl = solver.form_pinv_solve(nx, N, B, S, Pinv, gamma, lam, tol=1e-8, max_iter=100)
+        z = solver.recover_primal(nx, nu, N, B, Ginv, C, g, lam)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (S, gamma, Ginv, Pinv, lam, z, it, fl)]
+
+    want = by_hand()
+    S, gamma, Ginv, Pinv = (torch.full_like(t, float("nan")) for t in want[:4])
+    lam, z = torch.zeros_like(want[4]), torch.full_like(want[5], float("nan"))
+    r, p = torch.empty_like(lam), torch.empty_like(lam)
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    solver.kkt_step(nx, nu, N, B, G, C, g, c, S, gamma, Ginv, Pinv, lam, z, r=r, p=p, tol=1e-8, max_iter=100, iters=it, max_iter_exit=fl)
+    torch.cuda.synchronize()
+    for a, b in zip((S, gamma, Ginv, Pinv, lam, z, it, fl), want):
+        assert torch.equal(a, b)
+    assert int(fl.sum()) == 0
+    # the graph: new inputs written in place, lambda reset -> the by-hand results for those inputs
+    gr = solver.graph_kkt_step(nx, nu, N, B, G, C, g, c, S, gamma, Ginv, Pinv, lam, r, p, 1e-8, 100, it, fl, z)
+    for t, k in zip((G, C, g, c), "GCgc"):
+        t.copy_(dev(d2[k].reshape(-1)))
+    lam.zero_()
+    gr.launch()
+    torch.cuda.synchronize()
+    cold = it.clone()
+    want2 = by_hand()
+    for a, b in zip((S, gamma, Ginv, Pinv, lam, z, it, fl), want2):
+        assert torch.equal(a, b)
+    # warm start: the same system again from its own solution
+    gr.launch()
+    torch.cuda.synchronize()
+    assert bool((it <= cold).all()) and float(it.float().mean()) < 0.5 * float(cold.float().mean())
+    oz, _ = so.dense_kkt_solve(nx, nu, N, d2["G"][0], d2["C"][0], d2["g"][0], d2["c"][0])
+    zz = z.cpu().numpy().reshape(B, -1)[0]
+    assert np.linalg.norm(zz - oz) <= 3e-4 * np.linalg.norm(oz)   # exit test |eta| < 1e-8: a sanity bound, not the parity bar
+    gr.close()
+    assert td == z.dtype
