@@ -97,3 +97,15 @@ def test_batched_control_loop_example():
     out = subprocess.run([exe, "48", "100", "2"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "step 1:" in out.stdout and "||gamma - S lambda||" in out.stdout
+
+
+def test_kkt_step_loop_example():
+    """examples/kkt_step_loop.cpp: one graph replay per SQP step on the KKT blocks themselves (gbdpcg_graph_create_kkt_step_f32),
+    warm-started; the program checks both KKT residuals of what comes back in fp64 on the host and returns 0 only if they are
+    small and no problem ran out of iterations.  Horizons that are and are not a multiple of 4."""
+    exe = os.path.join(EX, "kkt_step_loop")
+    assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() makes it"
+    for args in (["40", "64", "3"], ["5", "19", "2"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "step 1:" in out.stdout and "stationarity" in out.stdout and out.stdout.strip().endswith("ok")
