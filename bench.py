@@ -71,6 +71,13 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def schur_traffic(kernel):
+    """HBM-side bytes per launch of a schur.hip kernel from the committed PMC passes of tools/schur_run.py."""
+    prof = profile_json("r02_schur_kernels.json")
+    rec = (prof or {}).get("kernels", {}).get(kernel)
+    return rec.get("traffic_bytes_per_launch") if rec else None
+
+
 def pmc_valu(kernel_prefix):
     """VALU-issue utilisation of a kernel from the committed SQ-counter pass (profiles/r02_pmc_sq.json, written by
     gbd-pcg_amd/tools/pmc_sq_json.py): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES per SIMD, LDS bank-conflict share."""
@@ -633,13 +640,13 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
     res = {"shape": {"stateSize": nx, "controlSize": nu, "knotPoints": N, "batch": B, "dtype": "f32"},
            "form_schur": {"kernel": "schur_form_quad_kernel<float,14,7>", "bound": "hbm", "us": t_form,
                           "algorithmic_bytes": by_form, "achieved": by_form / t_form / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                          "frac": by_form / t_form / 1e3 / HBM_PEAK_GBPS},
+                          "frac": by_form / t_form / 1e3 / HBM_PEAK_GBPS, "traffic": schur_traffic("schur_form_quad_kernel")},
            "form_pinv_solve": {"us": t_solve, "iters_mean": float(it.float().mean()), "tol": 1e-6,
                                "note": "stair Phi^-1 formed from S + PCG to tolerance, one graph (the formation's symmetry "
                                        "verdicts replace the solve's own test launch)"},
            "recover_primal": {"kernel": "schur_recover_quad_kernel<float,14,7>", "bound": "hbm", "us": t_rec,
                               "algorithmic_bytes": by_rec, "achieved": by_rec / t_rec / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": by_rec / t_rec / 1e3 / HBM_PEAK_GBPS},
+                              "frac": by_rec / t_rec / 1e3 / HBM_PEAK_GBPS, "traffic": schur_traffic("schur_recover_quad_kernel")},
            "us_per_step_of_1024_problems": t_all, "kkt_systems_per_sec": B / (t_all * 1e-6),
            "S_symmetric_in_storage": sym, "all_converged_and_finite": ok,
            "statistic": f"median of {reps} event-timed repetitions per stage, and of the whole step replayed as one hipGraph "

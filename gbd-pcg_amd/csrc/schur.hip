@@ -816,28 +816,42 @@ static uint32_t waves_for(const DeviceInfo &dev, size_t wave_bytes)
     return w;
 }
 
+// The block sizes the four-knots-per-wave kernels are built for: stateSize = 2 x joints, controlSize = joints (a manipulator's
+// positions and velocities against its torques; 14 / 7 is the BASELINE shape).  Other sizes take the any-size LDS kernels.
+#define GBDPCG_QUAD_SHAPES(X) X(4, 2) X(6, 3) X(8, 4) X(12, 6) X(14, 7)
+
+template <typename T, int NX, int NU>
+hipError_t launch_form_quad(const DeviceInfo &dev, uint32_t N, uint32_t batch, const T *G, const T *C, const T *g, const T *c, T *S,
+                            T *gamma, T *Ginv, hipStream_t s)
+{
+    using Q = QuadGeom<T, NX, NU>;
+    // one run per problem when the batch alone fills the device, shorter runs (each pays one silent step) otherwise
+    // (runs are multiples of 4 knots that divide knotPoints: other horizons are one run, the last step partly empty)
+    uint32_t run = N;
+    while (run % 8 == 0 && (uint64_t)batch * (N / run) < 4ull * dev.num_cus) run /= 2;
+    const uint64_t nwaves = (uint64_t)batch * (N / run);
+    if (nwaves > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)Q::TOTAL * sizeof(T);
+    auto kern = schur_form_quad_kernel<T, NX, NU>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((uint32_t)nwaves), dim3(64), lds, s, N, run, (uint32_t)nwaves, G, C, g, c, S, gamma, Ginv);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_form_schur(const DeviceInfo &dev, uint32_t nx, uint32_t nu, uint32_t N, uint32_t batch, const T *G, const T *C,
                              const T *g, const T *c, T *S, T *gamma, T *Ginv, hipStream_t s)
 {
     // GBDPCG_SCHUR_GENERAL=1: the any-size kernel also where the four-knots-per-wave form exists (A/B runs, tests)
     const char *env = getenv("GBDPCG_SCHUR_GENERAL");
-    if (nx == 14 && nu == 7 && !(env && env[0] == '1')) {
-        using Q = QuadGeom<T, 14, 7>;
-        // one run per problem when the batch alone fills the device, shorter runs (each pays one silent step) otherwise
-        // (runs are multiples of 4 knots that divide knotPoints: other horizons are one run, the last step partly empty)
-        uint32_t run = N;
-        while (run % 8 == 0 && (uint64_t)batch * (N / run) < 4ull * dev.num_cus) run /= 2;
-        const uint64_t nwaves = (uint64_t)batch * (N / run);
-        if (nwaves > 0x7fffffffull) return hipErrorInvalidValue;
-        const size_t lds = (size_t)Q::TOTAL * sizeof(T);
-        auto kern = schur_form_quad_kernel<T, 14, 7>;
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3((uint32_t)nwaves), dim3(64), lds, s, N, run, (uint32_t)nwaves, G, C, g, c, S, gamma, Ginv);
-        return hipGetLastError();
+    if (!(env && env[0] == '1')) {
+#define GBDPCG_X(NX, NU) \
+    if (nx == NX && nu == NU) return launch_form_quad<T, NX, NU>(dev, N, batch, G, C, g, c, S, gamma, Ginv, s);
+        GBDPCG_QUAD_SHAPES(GBDPCG_X)
+#undef GBDPCG_X
     }
     const size_t wave_bytes = (size_t)schur_wave_elems(nx, nu) * sizeof(T);
     const uint32_t waves = waves_for(dev, wave_bytes);
@@ -862,11 +876,16 @@ hipError_t launch_recover_primal(const DeviceInfo &dev, uint32_t nx, uint32_t nu
     const uint64_t rows = (uint64_t)batch * N;
     // GBDPCG_SCHUR_GENERAL=1: the any-size kernel also where the four-rows-per-wave form exists (A/B runs, tests)
     const char *env = getenv("GBDPCG_SCHUR_GENERAL");
-    if (nx == 14 && nu == 7 && !(env && env[0] == '1')) {
+    if (!(env && env[0] == '1')) {
         const uint64_t grid = (rows + 15) / 16;   // 4 waves x 4 rows per workgroup
         if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((schur_recover_quad_kernel<T, 14, 7>), dim3((uint32_t)grid), dim3(256), 0, s, N, rows, Ginv, C, g, lambda, z);
-        return hipGetLastError();
+#define GBDPCG_X(NX, NU)                                                                                                              \
+    if (nx == NX && nu == NU) {                                                                                                       \
+        hipLaunchKernelGGL((schur_recover_quad_kernel<T, NX, NU>), dim3((uint32_t)grid), dim3(256), 0, s, N, rows, Ginv, C, g, lambda, z); \
+        return hipGetLastError();                                                                                                     \
+    }
+        GBDPCG_QUAD_SHAPES(GBDPCG_X)
+#undef GBDPCG_X
     }
     const size_t wave_bytes = (size_t)recover_wave_elems(nx, nu) * sizeof(T);
     const uint32_t waves = waves_for(dev, wave_bytes);

@@ -18,6 +18,7 @@ import os
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SIMDS = 256 * 4   # MI355X: 256 CUs x 4 SIMDs
 
@@ -58,6 +59,43 @@ def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "gbd-pcg_amd", "tools", "pmc_traffic.py"),
                            os.path.join(src, "fetch"), os.path.join(src, "write"), os.path.join(src, "cal"),
                            os.path.join(dst, f"{rnd}_pmc_traffic.json")], stdout=subprocess.DEVNULL)
+    # the steps either side of the solve (schur.hip): stage times + kernel stats + traffic of tools/schur_run.py
+    st = os.path.join(src, "schur.txt")
+    if os.path.exists(st):
+        nx, nu, N, B = 14, 7, 128, 1024
+        alg = {"schur_form_quad_kernel": B * N * (2 * (nx * nx + nu * nu) + nx * nx + nx * nu + 2 * nx + nu + 3 * nx * nx + nx) * 4,
+               "schur_recover_quad_kernel": B * N * ((nx * nx + nu * nu) + nx * nx + nx * nu + 2 * (nx + nu) + nx) * 4}
+        rec = {"_how": "gbd-pcg_amd/tools/schur_run.py (1024 problems, stateSize 14, controlSize 7, knotPoints 128, fp32) under rocprofv3 "
+                       "--kernel-trace --stats, and in separate passes --pmc FETCH_SIZE / --pmc WRITE_SIZE (KiB; reads x2: the gfx950 "
+                       "correction of pmc_traffic.json); algorithmic bytes = every input once + every output once (to the knot: the "
+                       "last knot of a problem has no R, A, B, r)", "kernels": {}}
+        stats = glob.glob(os.path.join(src, "schur_stats", "**", "*kernel_stats.csv"), recursive=True)
+        avg = {}
+        for f in stats:
+            for row in csv.DictReader(open(f)):
+                for k in alg:
+                    if k in row["Name"]:
+                        avg[k] = (float(row["AverageNs"]), int(row["Calls"]))
+        import pmc_traffic
+        fetch = pmc_traffic.per_kernel(os.path.join(src, "schur_fetch"), "FETCH_SIZE")
+        write = pmc_traffic.per_kernel(os.path.join(src, "schur_write"), "WRITE_SIZE")
+        for k, a in alg.items():
+            f, _ = pmc_traffic.pick(fetch, k)
+            w, _ = pmc_traffic.pick(write, k)
+            r = {"algorithmic_bytes_per_launch": a}
+            if k in avg:
+                r.update({"AverageNs": avg[k][0], "calls": avg[k][1], "GBps": a / avg[k][0], "frac_of_8TBps": a / avg[k][0] / 8000.0})
+            if f is not None and w is not None:
+                r.update({"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": 2 * f * 1024 + w * 1024,
+                          "traffic_over_algorithmic": (2 * f * 1024 + w * 1024) / a})
+            rec["kernels"][k] = r
+        json.dump(rec, open(os.path.join(dst, f"{rnd}_schur_kernels.json"), "w"), indent=1)
+        with open(os.path.join(dst, f"{rnd}_schur.txt"), "w") as f:
+            f.write("# gbd-pcg_amd/tools/schur_run.py on one MI355X: KKT blocks -> S, gamma, G^-1 (form_schur), stair Pinv, converged solve, lambda -> z\n"
+                    "# (recover_primal); event-timed medians, GB/s = every input once + every output once / time.  Shapes: the headline batch,\n"
+                    "# a horizon that is not a multiple of 4, fp64, block sizes without a four-knot kernel (the LDS kernels), then the phase stamps\n"
+                    "# of one step of the four-knot formation kernel (shader cycles; diagnostic build).\n")
+            f.write(open(st).read())
     # SQ counters
     out = {"_how": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU "
                    "SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE on `bench.py --steps 3 --warmup 1` "

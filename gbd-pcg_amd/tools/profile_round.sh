@@ -9,7 +9,7 @@ R=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
-[ -x gbd-pcg_amd/tools/bw_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 gbd-pcg_amd/tools/bw_probe.hip -o gbd-pcg_amd/tools/bw_probe || exit 1
+[ -x gbd-pcg_amd/tools/bw_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Iinclude gbd-pcg_amd/tools/bw_probe.hip -o gbd-pcg_amd/tools/bw_probe -Lgbd-pcg_amd/csrc -lgbdpcg -Wl,-rpath,'$ORIGIN/../csrc' || exit 1
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
 echo "[1/6] bench line"
@@ -47,6 +47,19 @@ echo "[10] the cluster kernel (general storage): time per iteration and fixed co
     GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_clstamps.so python3 $ROOT/gbd-pcg_amd/tools/cluster_stamps.py 128 1024 | tail -8
   fi
 } > $OUT/cluster.txt 2>/dev/null || true
+echo "[11] the steps either side of the solve (schur.hip): stage times, kernel stats, traffic, phase stamps"
+{
+  python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 40
+  python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 40 --N 50 --batch 2048
+  python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 20 --dtype f64
+  python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 20 --nx 12 --nu 4
+  if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_schurstamps.so ]; then
+    GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_schurstamps.so python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 5 --stamps
+  fi
+} > $OUT/schur.txt 2>/dev/null || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/schur_stats -- python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 40 > $OUT/schur_stats.log 2>&1 || { tail -5 $OUT/schur_stats.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/schur_fetch -- python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 3 > $OUT/schur_fetch.log 2>&1 || { tail -5 $OUT/schur_fetch.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/schur_write -- python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 3 > $OUT/schur_write.log 2>&1 || { tail -5 $OUT/schur_write.log; exit 1; }
 [ -x $ROOT/gbd-pcg_amd/tools/bin/hop_probe ] && $ROOT/gbd-pcg_amd/tools/bin/hop_probe > $OUT/hop_probe.txt 2>/dev/null || true
 # keep what the digest needs, drop the bulky traces
 find $OUT -name "*.db" -delete 2>/dev/null

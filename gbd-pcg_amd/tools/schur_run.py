@@ -78,9 +78,9 @@ def main():
         s.form_schur(nx, nu, N, B, G, C, g, c, S=S, gamma=gam2, Ginv=Ginv)
         torch.cuda.synchronize()
         st = gam2[-24:].view(torch.int64).cpu().tolist()[:10]
-        names = ["wait for the requests", "issue next requests", "fix-ups + sync", "columns into registers", "elimination + previous S stores",
-                 "carry", "W, V products", "rows + T product", "D, gamma", "G^-1 stores"]
-        out["stamps_cycles_100MHz"] = {names[i]: st[i + 1] - st[i] for i in range(9)}
+        names = ["wait for the requests", "issue next requests", "fix-ups + columns into registers", "elimination + previous S stores",
+                 "carry", "G^-1 in place, A / B from LDS, W, V products", "T product", "D, gamma", "G^-1 stores"]
+        out["stamps_shader_cycles"] = {names[i]: st[i + 1] - st[i] for i in range(9)}
         out["stamps_step_total"] = st[9] - st[0]
     print(json.dumps(out))
     s.close()

@@ -102,6 +102,34 @@ def test_four_knot_form_runs_of_every_length(solver, N, B):
         test_form_schur_and_recover_vs_oracle(solver, 14, 7, N, B, dtype, tol)
 
 
+QUAD_SHAPES = [(4, 2), (6, 3), (8, 4), (12, 6), (14, 7)]   # GBDPCG_QUAD_SHAPES of csrc/schur.hip
+
+
+@pytest.mark.parametrize("nx,nu", QUAD_SHAPES[:-1])
+@pytest.mark.parametrize("N,B", [(1, 2), (3, 1), (4, 5), (16, 3), (50, 2), (64, 33), (128, 1), (7, 400)])
+def test_four_knot_kernels_of_the_other_block_sizes(solver, monkeypatch, nx, nu, N, B):
+    """The four-knots-per-wave formation kernel and the register recovery kernel are built for stateSize = 2 x controlSize in
+    {4, 6, 8, 12, 14}: every size against the oracle (fp32 and fp64; whole runs, split runs, horizons that are not a multiple of
+    4), the recovery bit for bit against the any-size kernel, and nothing written behind the outputs."""
+    for dtype, tol in ((np.float32, 2e-4), (np.float64, 1e-11)):
+        test_form_schur_and_recover_vs_oracle(solver, nx, nu, N, B, dtype, tol)
+    d = so.gen(nx, nu, N, seed=9, batch=B, dtype=np.float32)
+    dG, dC, dg, dc = (dev(d[k].reshape(-1)) for k in "GCgc")
+    nS, ng, nG = B * 3 * nx * nx * N, B * nx * N, dG.numel()
+    big = [torch.full((m + 4096,), 777.0, dtype=torch.float32, device="cuda") for m in (nS, ng, nG)]
+    solver.form_schur(nx, nu, N, B, dG, dC, dg, dc, S=big[0], gamma=big[1], Ginv=big[2])
+    lam = torch.randn(ng, device="cuda")
+    zbig = torch.full((dg.numel() + 4096,), 777.0, dtype=torch.float32, device="cuda")
+    solver.recover_primal(nx, nu, N, B, big[2], dC, dg, lam, z=zbig)
+    monkeypatch.setenv("GBDPCG_SCHUR_GENERAL", "1")
+    zg = solver.recover_primal(nx, nu, N, B, big[2], dC, dg, lam)
+    monkeypatch.delenv("GBDPCG_SCHUR_GENERAL")
+    torch.cuda.synchronize()
+    for t, m in zip(big + [zbig], (nS, ng, nG, dg.numel())):
+        assert bool((t[m:] == 777.0).all()) and bool(torch.isfinite(t[:m]).all())
+    assert torch.equal(zbig[:dg.numel()], zg)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("N,B", [(1, 1), (3, 1), (37, 3), (128, 5), (5, 13)])
 def test_register_recover_kernel_is_bit_identical_with_the_general_one(solver, monkeypatch, N, B, dtype):
