@@ -166,32 +166,48 @@ __global__ __launch_bounds__(512) void pcg_resident_kernel(PcgArgs<T> a)
     }
 }
 
-// Taken whenever the shape fits (n = 14, fp32, N <= 72): the matrices are then read once per solve
-// instead of once per iteration.  The fp64 map (1 row per lane, N <= 32) is written but disabled: 168
-// matrix VGPRs plus the fp64 working set spill.  GBDPCG_NO_RESIDENT disables the path (tuning runs).
+// Taken whenever the shape fits: the matrices are then read once per solve instead of once per iteration.  Built for the even
+// block sizes below (fp32: two rows per lane; fp64: one row per lane, not for n = 14 -- 168 matrix VGPRs plus the fp64 working
+// set spill): n = 14 is BASELINE config 2 (N <= 72); the smaller blocks (stateSize of 2-6 joint arms) fit longer horizons
+// (n = 8: N <= 128, n = 4: N <= 256 in fp32) and leave room for several workgroups per compute unit.
+// GBDPCG_NO_RESIDENT disables the path (tuning runs).
+#define GBDPCG_RESIDENT_N(X) X(4) X(6) X(8) X(12) X(14)
+
 template <typename T> bool resident_shape(uint32_t n, uint32_t N)
 {
     static const bool off = getenv("GBDPCG_NO_RESIDENT") != nullptr;
-    if (off || n != 14 || sizeof(T) == 8) return false;
-    return N <= DenseGeom<T, 14, (sizeof(T) == 4 ? 2 : 1)>::MAX_KNOTS;
+    if (off) return false;
+    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
+#define GBDPCG_X(NN) \
+    if (n == NN) return !(sizeof(T) == 8 && NN == 14) && N <= DenseGeom<T, NN, RV>::MAX_KNOTS;
+    GBDPCG_RESIDENT_N(GBDPCG_X)
+#undef GBDPCG_X
+    return false;
 }
 
-template <typename T>
-bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
+// Workgroups of `kern` one compute unit holds at once (registers, LDS); asked once per kernel and LDS size class.
+template <typename K> static uint32_t resident_wgs_per_cu(K kern, uint32_t threads, size_t lds)
 {
-    if (!resident_shape<T>(a.n, a.N)) return false;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (int)threads, lds) != hipSuccess || nb < 1) nb = 1;
+    return (uint32_t)(nb > 4 ? 4 : nb);
+}
+
+template <typename T, int NN>
+static bool launch_pcg_resident_n(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
+{
     constexpr int RV = sizeof(T) == 4 ? 2 : 1;
-    using Dg = DenseGeom<T, 14, RV>;
+    using Dg = DenseGeom<T, NN, RV>;
     static_assert(2 * Dg::REGS <= 176, "resident matrices must leave registers for the solve");
     const uintptr_t al = RV * sizeof(T);
     if ((reinterpret_cast<uintptr_t>(a.S) % al) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % al)) return false;
     size_t lds = ((size_t)2 * align16<T>((a.N + 2) * a.n) + 2 * align16<T>(Dg::WAVES)) * sizeof(T);
-    uint32_t grid = (uint32_t)dev.num_cus;  // one resident workgroup owns a CU's register file
-    if (grid > a.batch) grid = a.batch;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && NN == 14) {
         static const bool no_staging = getenv("GBDPCG_RES_DIRECT_LOADS") != nullptr;   // tuning runs only
         const bool staged = !no_staging && !(reinterpret_cast<uintptr_t>(a.S) % 16) && !(a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 16);
         if (staged) {
+            uint32_t grid = (uint32_t)dev.num_cus;  // one resident workgroup owns a CU's register file
+            if (grid > a.batch) grid = a.batch;
             lds = (lds + 15) / 16 * 16 + dense_stage_lds_bytes<14, RV>();
             auto kern = pcg_resident_kernel<T, 14, RV, true>;
             *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -201,9 +217,38 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
             return true;
         }
     }
-    hipLaunchKernelGGL((pcg_resident_kernel<T, 14, RV>), dim3(grid), dim3(Dg::WAVES * 64), lds, s, a);
+    auto kern = pcg_resident_kernel<T, NN, RV>;
+    // the smaller blocks need few registers: several workgroups share a compute unit and fill each other's barrier waits
+    // (one count per LDS size class of 8 KB; the kernel's registers do not depend on the horizon)
+    static uint32_t per_cu[32] = {};
+    const uint32_t cls = (uint32_t)(lds >> 13) < 31u ? (uint32_t)(lds >> 13) : 31u;
+    uint32_t w = __atomic_load_n(&per_cu[cls], __ATOMIC_RELAXED);
+    if (!w) {
+        w = resident_wgs_per_cu(kern, Dg::WAVES * 64, ((size_t)cls + 1) << 13);
+        __atomic_store_n(&per_cu[cls], w, __ATOMIC_RELAXED);
+    }
+    uint64_t grid = (uint64_t)dev.num_cus * w;
+    if (grid > a.batch) grid = a.batch;
+    if (lds > 48 * 1024) {
+        *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (*err != hipSuccess) return true;
+    }
+    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(Dg::WAVES * 64), lds, s, a);
     *err = hipGetLastError();
     return true;
+}
+
+template <typename T>
+bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
+{
+    if (!resident_shape<T>(a.n, a.N)) return false;
+#define GBDPCG_X(NN)                                                        \
+    if constexpr (!(sizeof(T) == 8 && NN == 14)) {                          \
+        if (a.n == NN) return launch_pcg_resident_n<T, NN>(dev, a, s, err); \
+    }
+    GBDPCG_RESIDENT_N(GBDPCG_X)
+#undef GBDPCG_X
+    return false;
 }
 
 template bool resident_shape<float>(uint32_t, uint32_t);

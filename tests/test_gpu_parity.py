@@ -251,6 +251,43 @@ def test_ragged_convergence_in_one_batch(solver, orc, path):
         assert relerr(out["lambda_"][b], ob[b]["lambda_"]) < F64_TOL
 
 
+RES_MAX = {np.float32: {4: 256, 6: 168, 8: 128, 12: 80}, np.float64: {4: 128, 6: 80, 8: 64, 12: 40}}   # DenseGeom::MAX_KNOTS
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [4, 6, 8, 12])
+def test_register_resident_kernel_of_the_small_blocks(solver, orc, dtype, n):
+    """pcg_resident_kernel is built for n in {4, 6, 8, 12} as well as 14 (fp32: two rows per lane, fp64: one): both matrices
+    in the registers of one workgroup for the whole solve, several workgroups per compute unit.  Against the oracle at the
+    longest horizon the block size allows, one knot beyond it (the streaming kernel takes over: same answers), one knot,
+    batches larger than the grid (every workgroup walks several problems), with and without a preconditioner, from a warm
+    start, and with r / p checked after a fixed number of iterations."""
+    tol = F64_TOL if dtype == np.float64 else F32_TOL
+    top = RES_MAX[dtype][n]
+    for N, B, pinv in ((top, 3, True), (top + 1, 2, True), (1, 5, True), (top // 2 + 1, 3, False), (9, 1300, True)):
+        d = synth.gen_numpy(n, N, seed=900 + n + N, batch=B, dtype=dtype)
+        P = d["Pinv"] if pinv else None
+        ob = orc.pcg_batch(n, N, B, d["S"], P, d["gamma"], tol=1e-6, max_iter=200)
+        out = gpu_solve(solver, n, N, B, d["S"], P, d["gamma"], tol=1e-6, max_iter=200)
+        if pinv:
+            assert np.array_equal(out["iters"], ob["iters"]) and not out["max_iter_exit"].any(), (N, B)
+        else:   # no preconditioner: the count is sensitive to the summation order (see test_randomized_dispatch_sweep)
+            assert (np.abs(out["iters"] - ob["iters"]) <= 3).all() and not out["max_iter_exit"].any(), (N, B)
+        for b in range(0, B, max(1, B // 7)):
+            assert relerr(out["lambda_"][b], ob["lambda_"][b]) < (tol if pinv else 30 * tol), (N, B, b)
+    # fixed iteration count: lambda, r and p after exactly 4 iterations, from a warm start
+    N, B = top - 3, 4
+    d = synth.gen_numpy(n, N, seed=77 + n, batch=B, dtype=dtype)
+    lam0 = (0.1 * np.random.default_rng(n).standard_normal((B, n * N))).astype(dtype)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=4, lambda0=lam0)
+    out = gpu_solve(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], lam0=lam0, tol=0.0, max_iter=4)
+    assert (out["iters"] == 4).all() and out["max_iter_exit"].all()
+    for k in ("lambda_", "r", "p"):
+        for b in range(B):
+            assert relerr(out[k][b], ob[k][b]) < 20 * tol, (k, b)
+    assert solver.choose_path(np.dtype(dtype).itemsize, n, top, 1) == binding.PATH_FUSED
+
+
 def test_auto_path_choice(solver):
     """BASELINE configs: 2 and 3 run fused (vectors fit one workgroup's LDS); 4 is spread over many CUs -- as ONE
     persistent launch when all its workgroups can be resident (one problem, or two), else two launches per iteration."""
