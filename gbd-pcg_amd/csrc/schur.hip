@@ -256,15 +256,53 @@ __device__ __forceinline__ void dma_4k(const void *base, uint32_t lane_off, uint
                  : "=&s"(keep) : "s"(base), "v"(lane_off), "s"(lds_addr) : "memory");
 }
 #undef GBDPCG_DMA_AT
+// One kilobyte per instruction (16 bytes per lane, lane16 = 16 * lane): global addresses need only be 4-byte aligned, like any
+// dwordx4 load; the LDS side (M0 + 16 * lane) is 16-byte aligned by construction of the buffers.
+#ifndef GBDPCG_SCHUR_PACKED
+#define GBDPCG_SCHUR_PACKED 1   // 0: one row per instruction in the elimination (A/B runs)
+#endif
+#ifndef GBDPCG_SCHUR_ST4
+#define GBDPCG_SCHUR_ST4 1      // 0: one element per lane and store in the write-outs (A/B runs)
+#endif
+#ifndef GBDPCG_SCHUR_DMA_X4
+#define GBDPCG_SCHUR_DMA_X4 1   // 0: dword requests only (A/B runs)
+#endif
+template <int COUNT> __device__ __forceinline__ void dma_x4(const void *base, uint32_t lane16, uint32_t lds_addr)
+{
+    static_assert(COUNT >= 1 && COUNT <= 4, "instruction offsets are 13 bits, signed");
+    unsigned keep;
+    if constexpr (COUNT == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(base), "v"(lane16), "s"(lds_addr) : "memory");
+    else if constexpr (COUNT == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(base), "v"(lane16), "s"(lds_addr) : "memory");
+    else if constexpr (COUNT == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:1024\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(base), "v"(lane16), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:1024\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(base), "v"(lane16), "s"(lds_addr) : "memory");
+}
 // A region of DWORDS dwords (LDS room: the next multiple of 64), every lane of every instruction active: the caller has checked
-// that the bytes up to the padded end exist in memory.
+// that the bytes up to the padded end exist in memory.  Whole kilobytes go as 16-byte requests, the rest as dwords.
 template <uint32_t DWORDS> __device__ __forceinline__ void dma_region(const void *base, uint32_t lane_off, uint32_t lds_addr)
 {
-    constexpr uint32_t INSTR = (DWORDS + 63) / 64;
+    constexpr uint32_t X4 = GBDPCG_SCHUR_DMA_X4 ? DWORDS / 256 : 0;   // instructions of 1 KB
+    constexpr uint32_t INSTR = (DWORDS - X4 * 256 + 63) / 64;        // dword instructions behind them
 #pragma unroll
-    for (uint32_t i = 0; i + 16 <= INSTR; i += 16) dma_4k(static_cast<const char *>(base) + i * 256, lane_off, lds_addr + i * 256);
+    for (uint32_t i = 0; i + 4 <= X4; i += 4) dma_x4<4>(static_cast<const char *>(base) + i * 1024, lane_off * 4, lds_addr + i * 1024);
+    if constexpr (X4 % 4 != 0) dma_x4<X4 % 4>(static_cast<const char *>(base) + (X4 / 4 * 4) * 1024, lane_off * 4, lds_addr + (X4 / 4 * 4) * 1024);
+    const char *rest = static_cast<const char *>(base) + X4 * 1024;
+    const uint32_t lrest = lds_addr + X4 * 1024;
 #pragma unroll
-    for (uint32_t i = INSTR / 16 * 16; i < INSTR; ++i) dma_dword(static_cast<const char *>(base) + i * 256, lane_off, lds_addr + i * 256);
+    for (uint32_t i = 0; i + 16 <= INSTR; i += 16) dma_4k(rest + i * 256, lane_off, lrest + i * 256);
+#pragma unroll
+    for (uint32_t i = INSTR / 16 * 16; i < INSTR; ++i) dma_dword(rest + i * 256, lane_off, lrest + i * 256);
 }
 
 // 1 / x: the hardware reciprocal and one Newton step in fp32 (the division sequence is a dozen dependent instructions on the
@@ -338,6 +376,25 @@ template <int J, int M, typename T> __device__ __forceinline__ void quad_pivot(T
     const bool is_j = l == (uint32_t)J;
     const T piv = quad_rcp(cj[J]);
     const T pr = is_j ? piv : col[J] * piv;
+#if GBDPCG_SCHUR_PACKED
+    if constexpr (sizeof(T) == 4) {
+        // two rows per instruction: the pivot lane's "start from zero" is a packed multiply by 0 or 1 (exact) instead of a select
+        // per row, the update a packed fma -- the same fma as below, element for element
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const float keep = is_j ? 0.0f : 1.0f;
+        const f2 kk = {keep, keep}, npr = {-pr, -pr};
+#pragma unroll
+        for (int r = 0; r + 1 < M; r += 2) {
+            const f2 c = {col[r], col[r + 1]}, b = {cj[r], cj[r + 1]};
+            const f2 v = __builtin_elementwise_fma(b, npr, c * kk);
+            col[r] = v.x;
+            col[r + 1] = v.y;
+        }
+        if constexpr (M & 1) col[M - 1] = fma_t(-cj[M - 1], pr, is_j ? T(0) : col[M - 1]);
+        col[J] = pr;
+        return;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < M; ++r) col[r] = (r == J) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
 }
@@ -369,7 +426,6 @@ template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t ZER = (GAM + 4 * NX + 3) & ~3u;      // CP zeros: the "columns" of the lanes that own none
     static constexpr uint32_t TOTAL = ZER + CP;
     static constexpr uint32_t SROW = 3 * NX * NX;
-    static constexpr uint32_t OUT_T = (4 * SROW + 63) / 64;       // trips of the S write-out
 };
 
 }  // namespace
@@ -397,15 +453,36 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     const T *Gp = G + (size_t)prob * d.szG, *Cp = C + (size_t)prob * d.szC, *gp = g + (size_t)prob * d.szg, *cp = c + (size_t)prob * d.szc;
 
     // where the elements this lane stores in the S write-out sit in LDS (the same every step)
-    uint32_t src[Q::OUT_T];
+    // The write-outs move SW consecutive elements per lane and store (one 16-byte store in fp32: a store instruction costs this
+    // kernel ~70 cycles of issue whatever its width -- 54 dword stores per step were a quarter of its time): OUT_T trips for the
+    // four S rows of a step, GI_T for the G^-1 of its four knots; ST_I store instructions per trip.
+    constexpr uint32_t SW = GBDPCG_SCHUR_ST4 ? 4 : 1, ST_I = SW * sizeof(T) > 16 ? SW * sizeof(T) / 16 : 1;
+    constexpr uint32_t OUT_T = (4 * Q::SROW / SW + 63) / 64, GI_T = (4 * Q::SG / SW + 63) / 64;
+    constexpr uint32_t S_STORES = OUT_T * ST_I + 1, GI_STORES = GI_T * ST_I;   // + 1: gamma
+    static_assert((4 * Q::SROW) % SW == 0 && Q::SROW % SW == 0 && (4 * Q::SG) % SW == 0, "whole groups");
+    typedef T OutV __attribute__((ext_vector_type(SW == 4 ? 4 : 2), aligned(sizeof(T))));   // (SW == 1 does not use it)
+    uint32_t src[OUT_T][SW];
 #pragma unroll
-    for (uint32_t t = 0; t < Q::OUT_T; ++t) {
-        const uint32_t e = t * 64 + lane;
-        const uint32_t q = e / Q::SROW, i = e - q * Q::SROW, slot = i / (NX * NX), ii = i - slot * (NX * NX), cc = ii / NX, r = ii - cc * NX;
-        src[t] = slot == 0 ? Q::WSL + q * (NX + 1) * CP + cc * CP + r
-                 : slot == 1 ? Q::DSL + q * NX * NX + ii
-                             : Q::WSL + (q + 1) * (NX + 1) * CP + r * CP + cc;
-    }
+    for (uint32_t t = 0; t < OUT_T; ++t)
+#pragma unroll
+        for (uint32_t u = 0; u < SW; ++u) {
+            const uint32_t e0 = (t * 64 + lane) * SW + u, e = e0 < 4 * Q::SROW ? e0 : 0u;
+            const uint32_t q = e / Q::SROW, i = e - q * Q::SROW, slot = i / (NX * NX), ii = i - slot * (NX * NX), cc = ii / NX, r = ii - cc * NX;
+            src[t][u] = slot == 0 ? Q::WSL + q * (NX + 1) * CP + cc * CP + r
+                        : slot == 1 ? Q::DSL + q * NX * NX + ii
+                                    : Q::WSL + (q + 1) * (NX + 1) * CP + r * CP + cc;
+        }
+    // SW elements from registers to memory (4-byte aligned addresses are fine for a 16-byte store, as for the loads)
+    auto put = [&](T *dst, const T (&v)[SW]) {
+        if constexpr (SW == 1) {
+            dst[0] = v[0];
+        } else {
+            OutV o;
+#pragma unroll
+            for (uint32_t u = 0; u < SW; ++u) o[u] = v[u];
+            *reinterpret_cast<OutV *>(dst) = o;
+        }
+    };
     // carry slots of a run that starts a problem: L_0 = 0, D_0 = Q_0^-1, gamma_0 = -(c_0 + Q_0^-1 q_0)
     // (written into the last quarter's slots: every step begins by moving those into slot 0)
     for (uint32_t i = lane; i < (NX + 1) * CP; i += 64) lds[Q::WSL + 4 * (NX + 1) * CP + i] = T(0);
@@ -458,7 +535,6 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #ifdef GBDPCG_SCHUR_STAMPS
     unsigned long long st[12] = {};
 #endif
-    constexpr uint32_t GI_T = (4 * Q::SG + 63) / 64;
     for (uint32_t jb = j_first; jb < j_end; jb += 4, b ^= 1u) {
         const bool emit = jb >= j_start;
 #ifdef GBDPCG_SCHUR_STAMPS
@@ -466,14 +542,14 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #endif
         SCHUR_STAMP(0);
         // The requests for this step were issued at the top of the previous one, before every store that step issued (the
-        // deferred S / gamma stores of the step before it: OUT_T + 1 instructions, and its own G^-1 stores: GI_T -- one
+        // deferred S / gamma stores of the step before it: S_STORES instructions, and its own G^-1 stores: GI_STORES -- a known number per
         // instruction per trip, which is why the write-out loops are written trip by trip), and the memory operations of a wave
         // retire in order: waiting until exactly that many are left is waiting for the requests and for nothing else.
-        static_assert(Q::OUT_T + 1 + GI_T <= 63, "vmcnt is a 6-bit counter");
+        static_assert(S_STORES + GI_STORES <= 63, "vmcnt is a 6-bit counter");
         switch (GBDPCG_SCHUR_SKIP & 4 ? 0u : stores_since_request) {
-        case Q::OUT_T + 1 + GI_T: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Q::OUT_T + 1 + GI_T) : "memory"); break;
-        case Q::OUT_T + 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Q::OUT_T + 1) : "memory"); break;
-        case GI_T: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GI_T) : "memory"); break;
+        case S_STORES + GI_STORES: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(S_STORES + GI_STORES) : "memory"); break;
+        case S_STORES: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(S_STORES) : "memory"); break;
+        case GI_STORES: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GI_STORES) : "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
         }
         stores_since_request = 0;
@@ -513,20 +589,22 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         // S and gamma of the PREVIOUS step leave now, a few stores after every pivot: all waves of the device walk in step, and
         // stores issued in one piece at the end of a step reach the memory system as one burst (14 MB) that the next requests
         // then queue behind
-        constexpr uint32_t PER = (Q::OUT_T + NX - 2) / (NX - 1);
-        static_assert(PER * (NX - 1) >= Q::OUT_T, "the last pivot's slot is gamma's");
-        T outv[Q::OUT_T + 1];
+        constexpr uint32_t PER = (OUT_T + NX - 2) / (NX - 1);
+        static_assert(PER * (NX - 1) >= OUT_T, "the last pivot's slot is gamma's");
+        T outv[OUT_T][SW], outg = T(0);
         if (pending) {   // one round trip for all of them, before the slots are touched
 #pragma unroll
-            for (uint32_t t = 0; t < Q::OUT_T; ++t) outv[t] = lds[src[t]];
-            outv[Q::OUT_T] = lds[Q::GAM + (lane < 4 * NX ? lane : 0u)];
-            stores_since_request += Q::OUT_T + 1;
+            for (uint32_t t = 0; t < OUT_T; ++t)
+#pragma unroll
+                for (uint32_t u = 0; u < SW; ++u) outv[t][u] = lds[src[t][u]];
+            outg = lds[Q::GAM + (lane < 4 * NX ? lane : 0u)];
+            stores_since_request += S_STORES;
         }
         auto drain = [&](uint32_t J) {
 #pragma unroll
-            for (uint32_t t = J * PER; t < (J + 1) * PER && t < Q::OUT_T; ++t)
-                if (J + 1 < NX && t * 64 + lane < 4 * Q::SROW) So_prev[t * 64 + lane] = outv[t];
-            if (J + 1 == NX && lane < 4 * NX) gam_prev[lane] = outv[Q::OUT_T];
+            for (uint32_t t = J * PER; t < (J + 1) * PER && t < OUT_T; ++t)
+                if (J + 1 < NX && (t * 64 + lane) * SW < 4 * Q::SROW) put(So_prev + (t * 64 + lane) * SW, outv[t]);
+            if (J + 1 == NX && lane < 4 * NX) gam_prev[lane] = outg;
         };
         if (!(GBDPCG_SCHUR_SKIP & 1)) {
             if (pending) quad_eliminate<0, NX, NU>(Qc, Rc, l, drain);
@@ -636,18 +714,18 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
                 T *Go = Ginv + (size_t)prob * d.szG + (size_t)jb * Q::SG;
                 const uint32_t lim = (uint32_t)(d.szG - (size_t)jb * Q::SG);
                 if (lim >= 4 * Q::SG) {   // every step but a problem's last: whole trips, the reads in one batch
-                    T gv[GI_T];
-#pragma unroll
-                    for (uint32_t t = 0; t < GI_T; ++t) gv[t] = raw[Q::RG + t * 64 + lane];
+                    T gv[GI_T][SW];
 #pragma unroll
                     for (uint32_t t = 0; t < GI_T; ++t)
-                        if (t * 64 + lane < 4 * Q::SG) Go[t * 64 + lane] = gv[t];
-                } else {
+#pragma unroll
+                        for (uint32_t u = 0; u < SW; ++u) gv[t][u] = raw[Q::RG + (t * 64 + lane) * SW + u];
 #pragma unroll
                     for (uint32_t t = 0; t < GI_T; ++t)
-                        if (t * 64 + lane < lim) Go[t * 64 + lane] = raw[Q::RG + t * 64 + lane];
+                        if ((t * 64 + lane) * SW < 4 * Q::SG) put(Go + (t * 64 + lane) * SW, gv[t]);
+                } else {   // (no request follows a problem's last step: the count below is not looked at again)
+                    for (uint32_t i = lane; i < lim; i += 64) Go[i] = raw[Q::RG + i];
                 }
-                stores_since_request += GI_T;
+                stores_since_request += GI_STORES;
             }
         }
 #ifdef GBDPCG_SCHUR_STAMPS
@@ -661,8 +739,13 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
     if (pending) {
         const uint32_t live = j_end == N && (N & 3u) ? (N & 3u) : 4u;
 #pragma unroll
-        for (uint32_t t = 0; t < Q::OUT_T; ++t)
-            if (t * 64 + lane < live * Q::SROW) So_prev[t * 64 + lane] = lds[src[t]];
+        for (uint32_t t = 0; t < OUT_T; ++t)
+            if ((t * 64 + lane) * SW < live * Q::SROW) {
+                T v[SW];
+#pragma unroll
+                for (uint32_t u = 0; u < SW; ++u) v[u] = lds[src[t][u]];
+                put(So_prev + (t * 64 + lane) * SW, v);
+            }
         if (lane < live * NX) gam_prev[lane] = lds[Q::GAM + lane];
     }
 #ifdef GBDPCG_SCHUR_STAMPS
