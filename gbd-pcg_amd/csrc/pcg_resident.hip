@@ -224,8 +224,13 @@ static bool launch_pcg_resident_n(const DeviceInfo &dev, const PcgArgs<T> &a, hi
     const uint32_t cls = (uint32_t)(lds >> 13) < 31u ? (uint32_t)(lds >> 13) : 31u;
     uint32_t w = __atomic_load_n(&per_cu[cls], __ATOMIC_RELAXED);
     if (!w) {
-        w = resident_wgs_per_cu(kern, Dg::WAVES * 64, ((size_t)cls + 1) << 13);
-        __atomic_store_n(&per_cu[cls], w, __ATOMIC_RELAXED);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            w = 1;   // no runtime query while a graph is being captured: this graph gets one workgroup per compute unit
+        } else {
+            w = resident_wgs_per_cu(kern, Dg::WAVES * 64, ((size_t)cls + 1) << 13);
+            __atomic_store_n(&per_cu[cls], w, __ATOMIC_RELAXED);
+        }
     }
     uint64_t grid = (uint64_t)dev.num_cus * w;
     if (grid > a.batch) grid = a.batch;

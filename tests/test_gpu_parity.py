@@ -286,6 +286,23 @@ def test_register_resident_kernel_of_the_small_blocks(solver, orc, dtype, n):
         for b in range(B):
             assert relerr(out[k][b], ob[k][b]) < 20 * tol, (k, b)
     assert solver.choose_path(np.dtype(dtype).itemsize, n, top, 1) == binding.PATH_FUSED
+    # the first launch of a shape may be the capture of a graph (the workgroups-per-CU query happens inside it)
+    N, B = max(2, top // 3), 7
+    d = synth.gen_numpy(n, N, seed=5 + n, batch=B, dtype=dtype)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    dS, dP, dg = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+    lam = torch.zeros_like(dg)
+    r, p = torch.empty_like(dg), torch.empty_like(dg)
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fl = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    gr = solver.graph_solve(n, N, B, dS, dP, dg, lam, r, p, 1e-6, 100, it, fl)
+    for _ in range(2):
+        lam.zero_()
+        gr.launch()
+        torch.cuda.synchronize()
+        assert np.array_equal(it.cpu().numpy().astype(np.int64), ob["iters"].astype(np.int64))
+        assert relerr(lam.cpu().numpy().reshape(B, -1)[B - 1], ob["lambda_"][B - 1]) < tol
+    gr.close()
 
 
 def test_auto_path_choice(solver):
