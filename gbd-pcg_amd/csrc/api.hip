@@ -493,6 +493,7 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
         gbdpcg_status st = ensure_sym_flags(h, verdict_bytes<T>(n, N, batch));
         if (st != GBDPCG_OK) return st;
     }
+    resident_prepare<T>(n, N);
     hipStream_t cs = nullptr;
     HIP_TRY(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     gbdpcg_graph *g = new (std::nothrow) gbdpcg_graph;

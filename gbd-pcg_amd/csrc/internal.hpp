@@ -107,6 +107,7 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
 // ---- pcg_resident.hip : both matrices register-resident, one 8-wave workgroup per problem.
 // Returns false when the shape is not eligible (then nothing was launched).
 template <typename T> bool resident_shape(uint32_t n, uint32_t N);  // shape handled by the resident kernel
+template <typename T> void resident_prepare(uint32_t n, uint32_t N);  // runtime queries of that kernel, outside any capture
 template <typename T>
 bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
 // Symmetric matrices resident on one CU (pcg_resident_sym.hip): n = 14, fp32, N <= 128, a.symmetric set.

@@ -193,6 +193,36 @@ template <typename K> static uint32_t resident_wgs_per_cu(K kern, uint32_t threa
     return (uint32_t)(nb > 4 ? 4 : nb);
 }
 
+// Workgroups per compute unit of pcg_resident_kernel<T, NN, RV> at this LDS size: one count per LDS size class of 8 KB (the
+// kernel's registers do not depend on the horizon), asked of the runtime once -- never while a graph is being captured
+// (query = false: an unknown class then counts as 1; gbdpcg_graph_create_* asks before it starts the capture).
+template <typename T, int NN> static uint32_t resident_per_cu(size_t lds, bool query)
+{
+    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
+    static uint32_t per_cu[32] = {};
+    const uint32_t cls = (uint32_t)(lds >> 13) < 31u ? (uint32_t)(lds >> 13) : 31u;
+    uint32_t w = __atomic_load_n(&per_cu[cls], __ATOMIC_RELAXED);
+    if (!w && query) {
+        w = resident_wgs_per_cu(pcg_resident_kernel<T, NN, RV>, DenseGeom<T, NN, RV>::WAVES * 64, ((size_t)cls + 1) << 13);
+        __atomic_store_n(&per_cu[cls], w, __ATOMIC_RELAXED);
+    }
+    return w ? w : 1u;
+}
+
+template <typename T> void resident_prepare(uint32_t n, uint32_t N)
+{
+    if (!resident_shape<T>(n, N)) return;
+    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
+    const size_t lds = ((size_t)2 * align16<T>((N + 2) * n) + 2 * align16<T>(8)) * sizeof(T);
+#define GBDPCG_X(NN)                                     \
+    if constexpr (!(sizeof(T) == 8 && NN == 14)) {       \
+        if (n == NN) (void)resident_per_cu<T, NN>(lds, true); \
+    }
+    GBDPCG_RESIDENT_N(GBDPCG_X)
+#undef GBDPCG_X
+    (void)RV;
+}
+
 template <typename T, int NN>
 static bool launch_pcg_resident_n(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
 {
@@ -219,19 +249,9 @@ static bool launch_pcg_resident_n(const DeviceInfo &dev, const PcgArgs<T> &a, hi
     }
     auto kern = pcg_resident_kernel<T, NN, RV>;
     // the smaller blocks need few registers: several workgroups share a compute unit and fill each other's barrier waits
-    // (one count per LDS size class of 8 KB; the kernel's registers do not depend on the horizon)
-    static uint32_t per_cu[32] = {};
-    const uint32_t cls = (uint32_t)(lds >> 13) < 31u ? (uint32_t)(lds >> 13) : 31u;
-    uint32_t w = __atomic_load_n(&per_cu[cls], __ATOMIC_RELAXED);
-    if (!w) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-            w = 1;   // no runtime query while a graph is being captured: this graph gets one workgroup per compute unit
-        } else {
-            w = resident_wgs_per_cu(kern, Dg::WAVES * 64, ((size_t)cls + 1) << 13);
-            __atomic_store_n(&per_cu[cls], w, __ATOMIC_RELAXED);
-        }
-    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    const uint32_t w = resident_per_cu<T, NN>(lds, !capturing);
     uint64_t grid = (uint64_t)dev.num_cus * w;
     if (grid > a.batch) grid = a.batch;
     if (lds > 48 * 1024) {
@@ -256,6 +276,8 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
     return false;
 }
 
+template void resident_prepare<float>(uint32_t, uint32_t);
+template void resident_prepare<double>(uint32_t, uint32_t);
 template bool resident_shape<float>(uint32_t, uint32_t);
 template bool resident_shape<double>(uint32_t, uint32_t);
 template bool launch_pcg_resident<float>(const DeviceInfo &, const PcgArgs<float> &, hipStream_t, hipError_t *);
