@@ -261,6 +261,10 @@ __device__ __forceinline__ void dma_4k(const void *base, uint32_t lane_off, uint
 #ifndef GBDPCG_SCHUR_PACKED
 #define GBDPCG_SCHUR_PACKED 1   // 0: one row per instruction in the elimination (A/B runs)
 #endif
+#ifndef GBDPCG_SCHUR_SINGLE
+#define GBDPCG_SCHUR_SINGLE 1   // 1: ONE input buffer, requested at the end of a step, D staged in the consumed A / B region: under 20 KB of LDS
+#endif                          //    per wave in fp32 -> two waves per SIMD cover each other's waits; 0: two buffers, the next step's inputs
+                                //    requested at the top of this one (one wave per SIMD)
 #ifndef GBDPCG_SCHUR_ST4
 #define GBDPCG_SCHUR_ST4 1      // 0: one element per lane and store in the write-outs (A/B runs)
 #endif
@@ -418,11 +422,15 @@ template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t DW = sizeof(T) / 4;
     static constexpr uint32_t pad(uint32_t elems) { return (elems * DW + 63) / 64 * 64 / DW; }
     static constexpr uint32_t RG = 0, RC = RG + pad(4 * SG), Rg = RC + pad(4 * SC), Rc = Rg + pad(4 * SV), RAW_P = Rc + pad(4 * NX);
-    static constexpr uint32_t WSL = 2 * RAW_P;                    // 5 slots of (NX+1) padded columns: -[W_j | A e_j]
+    static constexpr bool SINGLE = GBDPCG_SCHUR_SINGLE != 0 && sizeof(T) == 4;   // (fp64: 38 KB even so -- two buffers, one wave per SIMD)
+    static constexpr uint32_t WSL = (SINGLE ? 1 : 2) * RAW_P;     // 5 slots of (NX+1) padded columns: -[W_j | A e_j]
     static constexpr uint32_t TSL = WSL + 5 * (NX + 1) * CP;      // 5 slots of NX padded columns: T_j
     static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of one padded column: B f_j
-    static constexpr uint32_t DSL = VSL + 5 * CP;                 // 4 x NX*NX: D_j, unpadded column-major
-    static constexpr uint32_t GAM = DSL + 4 * NX * NX;
+    // 4 x NX*NX: D_j, unpadded column-major -- with one input buffer in the A / B region of the inputs, which the products have
+    // consumed by the time D is formed (pad(4 SC) >= 4 NX^2) and which the next request overwrites only after the write-out has
+    // read it
+    static constexpr uint32_t DSL = SINGLE ? RC : VSL + 5 * CP;
+    static constexpr uint32_t GAM = SINGLE ? VSL + 5 * CP : DSL + 4 * NX * NX;
     static constexpr uint32_t ZER = (GAM + 4 * NX + 3) & ~3u;      // CP zeros: the "columns" of the lanes that own none
     static constexpr uint32_t TOTAL = ZER + CP;
     static constexpr uint32_t SROW = 3 * NX * NX;
@@ -431,10 +439,9 @@ template <typename T, int NX, int NU> struct QuadGeom {
 }  // namespace
 
 template <typename T, int NX, int NU>
-__global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_t run, uint32_t waves, const T *__restrict__ G,
-                                                            const T *__restrict__ C, const T *__restrict__ g,
-                                                            const T *__restrict__ c, T *__restrict__ S, T *__restrict__ gamma,
-                                                            T *__restrict__ Ginv)
+__device__ __forceinline__ void schur_form_quad_body(uint32_t N, uint32_t run, uint32_t waves, const T *__restrict__ G,
+                                                     const T *__restrict__ C, const T *__restrict__ g, const T *__restrict__ c,
+                                                     T *__restrict__ S, T *__restrict__ gamma, T *__restrict__ Ginv)
 {
     using Q = QuadGeom<T, NX, NU>;
     static_assert(NX <= 15 && NU <= 15 && NU <= NX, "one knot per 16-lane quarter, one spare lane for the vector");
@@ -535,7 +542,13 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
 #ifdef GBDPCG_SCHUR_STAMPS
     unsigned long long st[12] = {};
 #endif
-    for (uint32_t jb = j_first; jb < j_end; jb += 4, b ^= 1u) {
+    constexpr bool SINGLE = Q::SINGLE;
+    T outv[OUT_T][SW], outg = T(0);   // S rows and gamma of the previous step: read at its end, stored during this step's elimination
+#pragma unroll
+    for (uint32_t t = 0; t < OUT_T; ++t)
+#pragma unroll
+        for (uint32_t u = 0; u < SW; ++u) outv[t][u] = T(0);
+    for (uint32_t jb = j_first; jb < j_end; jb += 4, b ^= (SINGLE ? 0u : 1u)) {
         const bool emit = jb >= j_start;
 #ifdef GBDPCG_SCHUR_STAMPS
         const bool stamp_now = blockIdx.x == 0 && jb == 20;
@@ -545,8 +558,9 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         // deferred S / gamma stores of the step before it: S_STORES instructions, and its own G^-1 stores: GI_STORES -- a known number per
         // instruction per trip, which is why the write-out loops are written trip by trip), and the memory operations of a wave
         // retire in order: waiting until exactly that many are left is waiting for the requests and for nothing else.
+        // (One input buffer: the requests were the last thing the previous step issued, so everything is waited for.)
         static_assert(S_STORES + GI_STORES <= 63, "vmcnt is a 6-bit counter");
-        switch (GBDPCG_SCHUR_SKIP & 4 ? 0u : stores_since_request) {
+        switch ((GBDPCG_SCHUR_SKIP & 4) || SINGLE ? 0u : stores_since_request) {
         case S_STORES + GI_STORES: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(S_STORES + GI_STORES) : "memory"); break;
         case S_STORES: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(S_STORES) : "memory"); break;
         case GI_STORES: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GI_STORES) : "memory"); break;
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         }
         stores_since_request = 0;
         SCHUR_STAMP(1);
-        if (jb + 4 < j_end && !(GBDPCG_SCHUR_SKIP & 8)) request(jb + 4, b ^ 1u);
+        if (!SINGLE && jb + 4 < j_end && !(GBDPCG_SCHUR_SKIP & 8)) request(jb + 4, b ^ 1u);
         SCHUR_STAMP(2);
         T *raw = lds + b * Q::RAW_P;
         T *rQ = raw + Q::RG + qd * Q::SG, *rR = rQ + NX * NX, *rA = raw + Q::RC + qd * Q::SC, *rB = rA + NX * NX;
@@ -591,15 +605,7 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         // then queue behind
         constexpr uint32_t PER = (OUT_T + NX - 2) / (NX - 1);
         static_assert(PER * (NX - 1) >= OUT_T, "the last pivot's slot is gamma's");
-        T outv[OUT_T][SW], outg = T(0);
-        if (pending) {   // one round trip for all of them, before the slots are touched
-#pragma unroll
-            for (uint32_t t = 0; t < OUT_T; ++t)
-#pragma unroll
-                for (uint32_t u = 0; u < SW; ++u) outv[t][u] = lds[src[t][u]];
-            outg = lds[Q::GAM + (lane < 4 * NX ? lane : 0u)];
-            stores_since_request += S_STORES;
-        }
+        if (pending) stores_since_request += S_STORES;
         auto drain = [&](uint32_t J) {
 #pragma unroll
             for (uint32_t t = J * PER; t < (J + 1) * PER && t < OUT_T; ++t)
@@ -607,9 +613,9 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
             if (J + 1 == NX && lane < 4 * NX) gam_prev[lane] = outg;
         };
         if (!(GBDPCG_SCHUR_SKIP & 1)) {
-            if (pending) quad_eliminate<0, NX, NU>(Qc, Rc, l, drain);
+            if (pending && !SINGLE) quad_eliminate<0, NX, NU>(Qc, Rc, l, drain);
             else quad_eliminate<0, NX, NU>(Qc, Rc, l, [](uint32_t) {});
-        } else if (pending) {
+        } else if (pending && !SINGLE) {
 #pragma unroll
             for (uint32_t J = 0; J < NX; ++J) drain(J);
         }
@@ -727,6 +733,28 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
                 }
                 stores_since_request += GI_STORES;
             }
+            // the S rows and gamma of this step, in one round trip, before their slots (and, with one input buffer, the inputs) are
+            // touched again
+#pragma unroll
+            for (uint32_t t = 0; t < OUT_T; ++t)
+#pragma unroll
+                for (uint32_t u = 0; u < SW; ++u) outv[t][u] = lds[src[t][u]];
+            outg = lds[Q::GAM + (lane < 4 * NX ? lane : 0u)];
+            if constexpr (SINGLE) {
+                // two waves per SIMD are out of step with each other: the rows leave at once (no 40 registers held through the
+                // next step's elimination, which is what lets two waves fit)
+                const uint32_t live = jb + 4 > N ? N - jb : 4u;
+#pragma unroll
+                for (uint32_t t = 0; t < OUT_T; ++t)
+                    if ((t * 64 + lane) * SW < live * Q::SROW) put(So_prev + (t * 64 + lane) * SW, outv[t]);
+                if (lane < live * NX) gam_prev[lane] = outg;
+                pending = false;
+            }
+        }
+        if (SINGLE && jb + 4 < j_end && !(GBDPCG_SCHUR_SKIP & 8)) {
+            // nothing orders an LDS read behind an LDS-DMA write: every read of the buffer has returned before the requests go out
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            request(jb + 4, 0);
         }
 #ifdef GBDPCG_SCHUR_STAMPS
         {
@@ -740,13 +768,8 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         const uint32_t live = j_end == N && (N & 3u) ? (N & 3u) : 4u;
 #pragma unroll
         for (uint32_t t = 0; t < OUT_T; ++t)
-            if ((t * 64 + lane) * SW < live * Q::SROW) {
-                T v[SW];
-#pragma unroll
-                for (uint32_t u = 0; u < SW; ++u) v[u] = lds[src[t][u]];
-                put(So_prev + (t * 64 + lane) * SW, v);
-            }
-        if (lane < live * NX) gam_prev[lane] = lds[Q::GAM + lane];
+            if ((t * 64 + lane) * SW < live * Q::SROW) put(So_prev + (t * 64 + lane) * SW, outv[t]);
+        if (lane < live * NX) gam_prev[lane] = outg;
     }
 #ifdef GBDPCG_SCHUR_STAMPS
     if (blockIdx.x == 0 && lane == 0) {
@@ -755,6 +778,23 @@ __global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_
         for (int i = 0; i < 12; ++i) out[i] = st[i];
     }
 #endif
+}
+
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(64) void schur_form_quad_kernel(uint32_t N, uint32_t run, uint32_t waves, const T *__restrict__ G,
+                                                            const T *__restrict__ C, const T *__restrict__ g,
+                                                            const T *__restrict__ c, T *__restrict__ S, T *__restrict__ gamma,
+                                                            T *__restrict__ Ginv)
+{
+    schur_form_quad_body<T, NX, NU>(N, run, waves, G, C, g, c, S, gamma, Ginv);
+}
+// The form with one input buffer (fp32): held to 256 registers so that two waves share a SIMD.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void schur_form_quad2_kernel(
+    uint32_t N, uint32_t run, uint32_t waves, const float *__restrict__ G, const float *__restrict__ C, const float *__restrict__ g,
+    const float *__restrict__ c, float *__restrict__ S, float *__restrict__ gamma, float *__restrict__ Ginv)
+{
+    schur_form_quad_body<float, NX, NU>(N, run, waves, G, C, g, c, S, gamma, Ginv);
 }
 
 // z = -G^-1 (g + C' lambda): x_k = -Q_k^-1 (q_k + lambda_k - A_k' lambda_{k+1}),  u_k = -R_k^-1 (r_k - B_k' lambda_{k+1}).
@@ -911,11 +951,13 @@ hipError_t launch_form_quad(const DeviceInfo &dev, uint32_t N, uint32_t batch, c
     // one run per problem when the batch alone fills the device, shorter runs (each pays one silent step) otherwise
     // (runs are multiples of 4 knots that divide knotPoints: other horizons are one run, the last step partly empty)
     uint32_t run = N;
-    while (run % 8 == 0 && (uint64_t)batch * (N / run) < 4ull * dev.num_cus) run /= 2;
+    const uint64_t want = (Q::SINGLE ? 8ull : 4ull) * dev.num_cus;   // waves that fit the device at once
+    while (run % 8 == 0 && (uint64_t)batch * (N / run) < want) run /= 2;
     const uint64_t nwaves = (uint64_t)batch * (N / run);
     if (nwaves > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)Q::TOTAL * sizeof(T);
-    auto kern = schur_form_quad_kernel<T, NX, NU>;
+    void (*kern)(uint32_t, uint32_t, uint32_t, const T *, const T *, const T *, const T *, T *, T *, T *) = schur_form_quad_kernel<T, NX, NU>;
+    if constexpr (Q::SINGLE) kern = schur_form_quad2_kernel<NX, NU>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
