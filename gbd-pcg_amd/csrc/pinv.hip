@@ -594,15 +594,20 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
     }
     __syncthreads();
 
-    // ---- D slots (and the two corner blocks nobody reads): this workgroup owns knots k0 .. k0+14, and N-1 if it is the last
+    // ---- D slots: this workgroup owns knots k0 .. k0+14, and N-1 if it is the last.  D'_k leaves with R'_k and L'_{k+1} of its
+    // pair below -- the three are one contiguous run of 3 n^2 elements, and memory that sees D' now and the other two blocks of
+    // the row ten microseconds later pays for the row twice.  Here: the knot that ends the problem (it starts no pair) and the
+    // two corner blocks nobody reads.
     const uint32_t own_end = (chunk == chunks - 1) ? N : min(N, k0 + PAIRS);
-    for (uint32_t e = threadIdx.x; e < (own_end - k0) * nn; e += kPinvThreads) {
-        const uint32_t q = e / nn, i = e - q * nn, k = k0 + q;
-        T *o = Pinv + pbase + (size_t)k * 3 * nn;
-        o[nn + i] = inv[q][i];
-        if (k == 0) o[i] = T(0);
-        if (k == N - 1) o[2 * nn + i] = T(0);
+    if (own_end == N) {
+        T *o = Pinv + pbase + (size_t)(N - 1) * 3 * nn;
+        for (uint32_t i = threadIdx.x; i < nn; i += kPinvThreads) {
+            o[nn + i] = inv[N - 1 - k0][i];
+            o[2 * nn + i] = T(0);
+        }
     }
+    if (k0 == 0)
+        for (uint32_t i = threadIdx.x; i < nn; i += kPinvThreads) Pinv[pbase + i] = T(0);
 
     // ---- pass 2: pairs (k, k+1), k = k0 + j, j = wave, wave + 4, ...
     T *B = work[wave][0], *Wt = work[wave][1];
@@ -614,17 +619,26 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
         const uint32_t k = k0 + j;
         const T *A = inv[j], *C = inv[j + 1];
         const size_t blk = pbase + (size_t)k * 3 * nn, nb = blk + (size_t)3 * nn;
+        // Both blocks are read as they lie in memory (a lane-strided read of L_{k+1}^T costs the address unit one cache line
+        // per lane: with the strided R' stores below, that was most of this phase) and L_{k+1} is transposed through LDS.
         T lt[EPL];
         bool differs = false;
 #pragma unroll
         for (uint32_t q = 0; q < EPL; ++q) {
             const uint32_t i = lane + 64 * q;
             if (i < nn) {
+                B[i] = S[blk + 2 * (size_t)nn + i];   // R_k(r,c) at c n + r
+                Wt[i] = S[nb + i];                    // L_{k+1}, as stored
+            }
+        }
+        group_sync<64>();
+#pragma unroll
+        for (uint32_t q = 0; q < EPL; ++q) {
+            const uint32_t i = lane + 64 * q;
+            if (i < nn) {
                 const uint32_t c = i / n, r = i - c * n;
-                const T rk = S[blk + 2 * (size_t)nn + i];   // R_k(r,c)
-                lt[q] = S[nb + (size_t)r * n + c];          // L_{k+1}(c,r)
-                differs |= pinv_bits(rk) != pinv_bits(lt[q]);
-                B[i] = rk;
+                lt[q] = Wt[r * n + c];                // L_{k+1}(c,r)
+                differs |= pinv_bits(B[i]) != pinv_bits(lt[q]);
             }
         }
         const bool symmetric = __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
@@ -667,15 +681,24 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
                     x10 = fma_t(u1.x, y0.x, x10); x10 = fma_t(u1.y, y0.y, x10);
                     x11 = fma_t(u1.x, y1.x, x11); x11 = fma_t(u1.y, y1.y, x11);
                 }
-                if (pass == 0) {
-                    T *Rp = Pinv + blk + 2 * (size_t)nn;
-                    Rp[c0 * n + r0] = -x00; Rp[c0 * n + r0 + 1] = -x10;
-                    Rp[(c0 + 1) * n + r0] = -x01; Rp[(c0 + 1) * n + r0 + 1] = -x11;
-                }
-                if (pass == 1 || symmetric) {
-                    T *Lp = Pinv + nb;
-                    Lp[r0 * n + c0] = -x00; Lp[r0 * n + c0 + 1] = -x01;
-                    Lp[(r0 + 1) * n + c0] = -x10; Lp[(r0 + 1) * n + c0 + 1] = -x11;
+                // -X' into LDS in the layout of R' (column c0 of X' = row c0 of X ...): R'_k(r,c) = -X(c,r) at c n + r
+                Wt[c0 * n + r0] = -x00; Wt[c0 * n + r0 + 1] = -x10;
+                Wt[(c0 + 1) * n + r0] = -x01; Wt[(c0 + 1) * n + r0 + 1] = -x11;
+            }
+            group_sync<64>();
+            {   // dense stores: R'_k as it lies in Wt, L'_{k+1}(c,r) = R'_k(r,c) read transposed
+                T *Rp = Pinv + blk + 2 * (size_t)nn, *Lp = Pinv + nb;
+#pragma unroll
+                for (uint32_t q = 0; q < EPL; ++q) {
+                    const uint32_t i = lane + 64 * q;
+                    if (i < nn) {
+                        const uint32_t c = i / n, r = i - c * n;
+                        if (pass == 0) {
+                            Rp[i - (size_t)nn] = A[i];   // D'_k: the block in front of R'_k
+                            Rp[i] = Wt[i];
+                        }
+                        if (pass == 1 || symmetric) Lp[i] = Wt[r * n + c];
+                    }
                 }
             }
             group_sync<64>();
