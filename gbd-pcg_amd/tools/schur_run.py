@@ -78,8 +78,10 @@ def main():
         s.form_schur(nx, nu, N, B, G, C, g, c, S=S, gamma=gam2, Ginv=Ginv)
         torch.cuda.synchronize()
         st = gam2[-24:].view(torch.int64).cpu().tolist()[:10]
-        names = ["wait for the requests", "issue next requests", "fix-ups + columns into registers", "elimination + previous S stores",
-                 "carry", "G^-1 in place, A / B from LDS, W, V products", "T product", "D, gamma", "G^-1 stores"]
+        # fp32 (one input buffer): the requests for the next step go out at the END of a step, behind its stores, and the S rows are
+        # stored there too; fp64 (two buffers): requests at the top, S rows of the previous step stored during the elimination
+        names = ["wait for the requests", "(fp64: issue next requests)", "fix-ups + columns into registers", "elimination (fp64: + previous S stores)",
+                 "carry", "G^-1 in place, A / B from LDS, W, V products", "T product", "D, gamma", "G^-1 stores (fp32: + S, gamma stores, next requests)"]
         out["stamps_shader_cycles"] = {names[i]: st[i + 1] - st[i] for i in range(9)}
         out["stamps_step_total"] = st[9] - st[0]
     print(json.dumps(out))
