@@ -638,9 +638,9 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
     by_form = (2 * G.numel() + C.numel() + g.numel() + c.numel() + S.numel() + gamma.numel()) * 4
     by_rec = (Ginv.numel() + C.numel() + g.numel() + lam.numel() + z.numel()) * 4
     res = {"shape": {"stateSize": nx, "controlSize": nu, "knotPoints": N, "batch": B, "dtype": "f32"},
-           "form_schur": {"kernel": "schur_form_quad_kernel<float,14,7>", "bound": "hbm", "us": t_form,
+           "form_schur": {"kernel": "schur_form_quad2_kernel<14,7> (fp32: one input buffer, two waves per SIMD)", "bound": "hbm", "us": t_form,
                           "algorithmic_bytes": by_form, "achieved": by_form / t_form / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                          "frac": by_form / t_form / 1e3 / HBM_PEAK_GBPS, "traffic": schur_traffic("schur_form_quad_kernel")},
+                          "frac": by_form / t_form / 1e3 / HBM_PEAK_GBPS, "traffic": schur_traffic("schur_form_quad")},
            "form_pinv_solve": {"us": t_solve, "iters_mean": float(it.float().mean()), "tol": 1e-6,
                                "note": "stair Phi^-1 formed from S + PCG to tolerance, one graph (the formation's symmetry "
                                        "verdicts replace the solve's own test launch)"},

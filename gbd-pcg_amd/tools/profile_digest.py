@@ -40,6 +40,13 @@ def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
     dst = os.path.join(ROOT, "profiles")
+    # gpurun MERGES a call's output into gpurun_out/: files of an earlier profile round (other process ids in their names) stay
+    # behind next to the new ones.  Everything older than half an hour before the newest file is a leftover: removed.
+    files = [os.path.join(d, f) for d, _, fs in os.walk(src) for f in fs]
+    newest = max(os.path.getmtime(f) for f in files)
+    for f in files:
+        if os.path.getmtime(f) < newest - 1800:
+            os.remove(f)
     line = [ln for ln in open(os.path.join(src, "bench.json")) if ln.startswith("{")][-1]
     with open(os.path.join(dst, f"{rnd}_bench.jsonl"), "a") as f:
         f.write(line if line.endswith("\n") else line + "\n")
@@ -63,7 +70,7 @@ def main():
     st = os.path.join(src, "schur.txt")
     if os.path.exists(st):
         nx, nu, N, B = 14, 7, 128, 1024
-        alg = {"schur_form_quad_kernel": B * N * (2 * (nx * nx + nu * nu) + nx * nx + nx * nu + 2 * nx + nu + 3 * nx * nx + nx) * 4,
+        alg = {"schur_form_quad": B * N * (2 * (nx * nx + nu * nu) + nx * nx + nx * nu + 2 * nx + nu + 3 * nx * nx + nx) * 4,
                "schur_recover_quad_kernel": B * N * ((nx * nx + nu * nu) + nx * nx + nx * nu + 2 * (nx + nu) + nx) * 4}
         rec = {"_how": "gbd-pcg_amd/tools/schur_run.py (1024 problems, stateSize 14, controlSize 7, knotPoints 128, fp32) under rocprofv3 "
                        "--kernel-trace --stats, and in separate passes --pmc FETCH_SIZE / --pmc WRITE_SIZE (KiB; reads x2: the gfx950 "
