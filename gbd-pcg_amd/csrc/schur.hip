@@ -265,6 +265,9 @@ __device__ __forceinline__ void dma_4k(const void *base, uint32_t lane_off, uint
 #define GBDPCG_SCHUR_SINGLE 1   // 1: ONE input buffer, requested at the end of a step, D staged in the consumed A / B region: under 20 KB of LDS
 #endif                          //    per wave in fp32 -> two waves per SIMD cover each other's waits; 0: two buffers, the next step's inputs
                                 //    requested at the top of this one (one wave per SIMD)
+#ifndef GBDPCG_SCHUR_NT
+#define GBDPCG_SCHUR_NT 1       // 0: default cache policy for the 16-byte stores of S and G^-1 (A/B runs)
+#endif
 #ifndef GBDPCG_SCHUR_ST4
 #define GBDPCG_SCHUR_ST4 1      // 0: one element per lane and store in the write-outs (A/B runs)
 #endif
@@ -487,7 +490,11 @@ __device__ __forceinline__ void schur_form_quad_body(uint32_t N, uint32_t run, u
             OutV o;
 #pragma unroll
             for (uint32_t u = 0; u < SW; ++u) o[u] = v[u];
+#if GBDPCG_SCHUR_NT
+            __builtin_nontemporal_store(o, reinterpret_cast<OutV *>(dst));
+#else
             *reinterpret_cast<OutV *>(dst) = o;
+#endif
         }
     };
     // carry slots of a run that starts a problem: L_0 = 0, D_0 = Q_0^-1, gamma_0 = -(c_0 + Q_0^-1 q_0)
