@@ -425,7 +425,7 @@ template <typename T, int NX, int NU> struct QuadGeom {
     static constexpr uint32_t DW = sizeof(T) / 4;
     static constexpr uint32_t pad(uint32_t elems) { return (elems * DW + 63) / 64 * 64 / DW; }
     static constexpr uint32_t RG = 0, RC = RG + pad(4 * SG), Rg = RC + pad(4 * SC), Rc = Rg + pad(4 * SV), RAW_P = Rc + pad(4 * NX);
-    static constexpr bool SINGLE = GBDPCG_SCHUR_SINGLE != 0 && sizeof(T) == 4;   // (fp64: 38 KB even so -- two buffers, one wave per SIMD)
+    static constexpr bool SINGLE = GBDPCG_SCHUR_SINGLE != 0;   // (fp64: 38 KB even so -- one wave per SIMD, but on every SIMD: with two buffers, 65 KB, half of them idle)
     static constexpr uint32_t WSL = (SINGLE ? 1 : 2) * RAW_P;     // 5 slots of (NX+1) padded columns: -[W_j | A e_j]
     static constexpr uint32_t TSL = WSL + 5 * (NX + 1) * CP;      // 5 slots of NX padded columns: T_j
     static constexpr uint32_t VSL = TSL + 5 * NX * CP;            // 5 slots of one padded column: B f_j
@@ -958,13 +958,15 @@ hipError_t launch_form_quad(const DeviceInfo &dev, uint32_t N, uint32_t batch, c
     // one run per problem when the batch alone fills the device, shorter runs (each pays one silent step) otherwise
     // (runs are multiples of 4 knots that divide knotPoints: other horizons are one run, the last step partly empty)
     uint32_t run = N;
-    const uint64_t want = (Q::SINGLE ? 8ull : 4ull) * dev.num_cus;   // waves that fit the device at once
+    const size_t lds_wave = (size_t)Q::TOTAL * sizeof(T);
+    const uint64_t fit = lds_wave ? (160u * 1024u) / lds_wave : 8u;   // waves of this kernel a compute unit's LDS holds
+    const uint64_t want = (fit > 8 ? 8 : (fit < 1 ? 1 : fit)) * dev.num_cus;   // ... and the device, at two per SIMD at most
     while (run % 8 == 0 && (uint64_t)batch * (N / run) < want) run /= 2;
     const uint64_t nwaves = (uint64_t)batch * (N / run);
     if (nwaves > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)Q::TOTAL * sizeof(T);
     void (*kern)(uint32_t, uint32_t, uint32_t, const T *, const T *, const T *, const T *, T *, T *, T *) = schur_form_quad_kernel<T, NX, NU>;
-    if constexpr (Q::SINGLE) kern = schur_form_quad2_kernel<NX, NU>;
+    if constexpr (Q::SINGLE && sizeof(T) == 4) kern = schur_form_quad2_kernel<NX, NU>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
