@@ -106,3 +106,22 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          capture_output=True, text=True, timeout=60, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_kkt_generator_shapes_and_determinism():
+    """synth.kkt_torch (input of bench.py's mpc_step block and of tools/schur_run.py): packed sizes of include/gbdpcg.h, the same
+    blocks for the same seed, symmetric positive definite cost blocks."""
+    import numpy as np
+    import torch
+    from gbd_pcg_amd import synth
+    nx, nu, N, B = 6, 3, 5, 2
+    a = synth.kkt_torch(nx, nu, N, B, "cpu", torch.float64, seed=3)
+    b = synth.kkt_torch(nx, nu, N, B, "cpu", torch.float64, seed=3)
+    sizes = [B * ((nx * nx + nu * nu) * N - nu * nu), B * (nx * nx + nx * nu) * (N - 1), B * ((nx + nu) * N - nu), B * nx * N]
+    assert [t.numel() for t in a] == sizes and all(torch.equal(x, y) for x, y in zip(a, b))
+    G = a[0].reshape(B, -1).numpy()
+    for k in range(N):
+        Q = G[0, k * (nx * nx + nu * nu):][:nx * nx].reshape(nx, nx)
+        assert np.allclose(Q, Q.T) and np.linalg.eigvalsh(Q).min() >= 1.0 - 1e-9
+    one = synth.kkt_torch(nx, nu, 1, B, "cpu", torch.float32)
+    assert one[1].numel() == 0 and one[0].numel() == B * nx * nx
