@@ -20,6 +20,10 @@
 #include "bt_device.hpp"
 #include "internal.hpp"
 
+#ifndef GBDPCG_PINV_DPP
+#define GBDPCG_PINV_DPP 1   // 0: pivot columns of the one-launch stair kernel broadcast through LDS (A/B runs)
+#endif
+
 namespace gbdpcg {
 
 constexpr int kPinvThreads = 256;
@@ -273,6 +277,37 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_pair_kernel(uint32_t N
     }
 }
 
+// The value lane J of every 16-lane row holds, in all lanes of that row (DPP row_newbcast: a VALU move, no LDS round trip), and the
+// in-place Gauss-Jordan elimination of an M x M block held one column per lane on top of it -- the arithmetic of
+// pinv_diag_quad_kernel, element for element (the broadcast values are the same numbers that kernel passes through LDS).
+#if GBDPCG_PINV_DPP
+template <int J> __device__ __forceinline__ float stair_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + J, 0xf, 0xf, true));
+}
+template <int J> __device__ __forceinline__ double stair_bcast(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + J, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int J, int M, typename T> __device__ __forceinline__ void stair_eliminate(T (&col)[M], uint32_t l)
+{
+    if constexpr (J < M) {
+        T cj[M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) cj[r] = stair_bcast<J>(col[r]);
+        const T piv = T(1) / cj[J];
+        const bool is_j = l == (uint32_t)J;
+        const T pr = is_j ? piv : col[J] * piv;
+#pragma unroll
+        for (int r = 0; r < M; ++r) col[r] = (r == J) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+        stair_eliminate<J + 1, M>(col, l);
+    }
+}
+#endif
+
 // n <= 16: FOUR knots per wavefront, one per 16-lane quarter, with the IN-PLACE form of the same
 // elimination: lane c < n of a quarter owns column c of the n x n block only.  The identity half of the
 // [D | I] tableau is never stored: its column j stays the unit vector e_j until pivot step j (its pivot-row
@@ -300,7 +335,13 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_diag_quad_kernel(uint32_t N
     T col[n];
 #pragma unroll
     for (uint32_t r = 0; r < n; ++r) col[r] = (kind == 0 || !alive || !owner) ? (r == l ? T(1) : T(0)) : D[l * n + r];
+#if GBDPCG_PINV_DPP
+    (void)bc;
+    if (kind != 0) stair_eliminate<0, (int)n>(col, l);
+    if (false) {
+#else
     if (kind != 0) {
+#endif
 #pragma unroll
         for (uint32_t j = 0; j < n; ++j) {
             if (l == j) {
@@ -566,6 +607,10 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
         T col[n];
 #pragma unroll
         for (uint32_t r = 0; r < n; ++r) col[r] = (!alive || !owner) ? (r == l ? T(1) : T(0)) : D[l * n + r];
+#if GBDPCG_PINV_DPP
+        (void)bc;
+        stair_eliminate<0, (int)n>(col, l);
+#else
 #pragma unroll
         for (uint32_t j = 0; j < n; ++j) {
             if (l == j) {
@@ -583,6 +628,7 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
 #pragma unroll
             for (uint32_t r = 0; r < n; ++r) col[r] = (r == j) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
         }
+#endif
         if (owner) {  // mirrored on the way into LDS: element (r, c) with r > c takes the value of (c, r)
 #pragma unroll
             for (uint32_t r = 0; r < n; ++r)
