@@ -103,6 +103,19 @@ def main():
                     "# a horizon that is not a multiple of 4, fp64, block sizes without a four-knot kernel (the LDS kernels), then the phase stamps\n"
                     "# of one step of the four-knot formation kernel (shader cycles; diagnostic build).\n")
             f.write(open(st).read())
+    # the kernels of one whole inner step (examples/kkt_step_loop under rocprofv3 --kernel-trace --stats)
+    ks = glob.glob(os.path.join(src, "kkt_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        rows = list(csv.reader(open(ks[0])))
+        keep = [rows[0]] + [r for r in rows[1:] if "gbdpcg" in r[0]]
+        with open(os.path.join(dst, f"{rnd}_kkt_step_kernel_stats.csv"), "w", newline="") as f:
+            csv.writer(f).writerows(keep)
+        lp = os.path.join(src, "kkt_step_loop.txt")
+        if os.path.exists(lp):
+            with open(os.path.join(dst, f"{rnd}_kkt_step_loop.txt"), "w") as f:
+                f.write("# gbd-pcg_amd/examples/kkt_step_loop 1024 128 20 under rocprofv3 --kernel-trace (one graph replay per step: KKT blocks -> S, gamma,\n"
+                        "# G^-1 -> stair Pinv -> PCG to |eta| < 1e-10, warm-started -> primal step; KKT residuals checked in fp64 on the host)\n")
+                f.write(open(lp).read())
     # SQ counters
     out = {"_how": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU "
                    "SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE on `bench.py --steps 3 --warmup 1` "

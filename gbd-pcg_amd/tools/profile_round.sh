@@ -60,6 +60,10 @@ echo "[11] the steps either side of the solve (schur.hip): stage times, kernel s
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/schur_stats -- python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 40 > $OUT/schur_stats.log 2>&1 || { tail -5 $OUT/schur_stats.log; exit 1; }
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/schur_fetch -- python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 3 > $OUT/schur_fetch.log 2>&1 || { tail -5 $OUT/schur_fetch.log; exit 1; }
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/schur_write -- python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 3 > $OUT/schur_write.log 2>&1 || { tail -5 $OUT/schur_write.log; exit 1; }
+echo "[12] the whole inner step as one graph (examples/kkt_step_loop): which kernels a step is made of"
+if [ -x $ROOT/gbd-pcg_amd/examples/kkt_step_loop ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kkt_stats -- $ROOT/gbd-pcg_amd/examples/kkt_step_loop 1024 128 20 > $OUT/kkt_step_loop.txt 2> $OUT/kkt_stats.log || { tail -5 $OUT/kkt_stats.log; exit 1; }
+fi
 [ -x $ROOT/gbd-pcg_amd/tools/bin/hop_probe ] && $ROOT/gbd-pcg_amd/tools/bin/hop_probe > $OUT/hop_probe.txt 2>/dev/null || true
 # keep what the digest needs, drop the bulky traces
 find $OUT -name "*.db" -delete 2>/dev/null
