@@ -11,6 +11,15 @@
 #include "bt_device.hpp"
 #include "internal.hpp"
 
+#ifndef GBDPCG_RES_OCC
+#define GBDPCG_RES_OCC 1   // 0: no register cap on the small-block instantiations of the resident kernel (A/B runs)
+#endif
+#if GBDPCG_RES_OCC
+#define GBDPCG_RES_OCC_ATTR __attribute__((amdgpu_waves_per_eu(NCT * sizeof(T) <= 32 || (NCT <= 6) ? 4 : 2)))   // n <= 8 in fp32, n <= 6 in fp64
+#else
+#define GBDPCG_RES_OCC_ATTR
+#endif
+
 namespace gbdpcg {
 
 // Workgroup-wide sum of per-lane partials; every thread returns the same bits (one barrier inside).
@@ -28,8 +37,10 @@ __device__ __forceinline__ T wg_sum_r(T part, T *red, uint32_t lane, uint32_t wa
 
 // STAGED (fp32, n = 14, matrices 16-byte aligned): the tiles come in through LDS-DMA staging buffers -- dense, coalesced
 // 16-byte pieces instead of 8 bytes per lane at a 56-byte stride (bt_dense.hpp, dense_staged_load).
+// (Blocks of 8 or fewer -- 6 in fp64, where n = 8 would spill 40 registers -- are held to 128 registers, so that two workgroups
+// share a compute unit: 1024 converged solves of n = 8, N = 128 take 105 instead of 119 us, n = 6, N = 80 in fp64 92 instead of 120.)
 template <typename T, int NCT, int V, bool STAGED = false>
-__global__ __launch_bounds__(512) void pcg_resident_kernel(PcgArgs<T> a)
+__global__ __launch_bounds__(512) GBDPCG_RES_OCC_ATTR void pcg_resident_kernel(PcgArgs<T> a)
 {
     using Dg = DenseGeom<T, NCT, V>;
     constexpr int WAVES = Dg::WAVES;
