@@ -114,6 +114,63 @@ template <typename T> static void run(const char *prec)
         snprintf(tag, sizeof tag, "%s csr_ident", prec);
         report(tag, it, lam);
     }
+    {   // the steps either side of the solve through the template layer: a 2-state, 1-control, 3-knot problem, printed for the
+        // test to hold against a dense solve of the whole KKT system ("kkt_z": z = (x_0, u_0, x_1, u_1, x_2); "kkt_step": lambda)
+        const uint32_t nx = 2, nu = 1, Nk = 3;
+        const T hG[] = {2, 0.5, 0.5, 1, 3,   1.5, 0.2, 0.2, 2, 1,   1, 0, 0, 4};           // Q_0 R_0 Q_1 R_1 Q_2 (column-major)
+        const T hC[] = {1, 0.1, -0.2, 0.9, 0.5, 1,   0.8, 0, 0.3, 1.1, 0, 0.7};             // A_0 B_0 A_1 B_1
+        const T hg[] = {1, -1, 0.5,   0.3, 0.2, -0.4,   -0.6, 0.9};                         // q_0 r_0 q_1 r_1 q_2
+        const T hc[] = {0.5, -0.25,   0.1, 0.2,   -0.3, 0.05};                              // c_0 c_1 c_2
+        T *dG, *dC, *dg, *dc, *dS, *dgam, *dGi, *dP, *dl, *dz;
+        uint32_t *d_it;
+        uint8_t *d_fl;
+        gpuErrchk(hipMalloc((void **)&dG, sizeof hG));
+        gpuErrchk(hipMalloc((void **)&dC, sizeof hC));
+        gpuErrchk(hipMalloc((void **)&dg, sizeof hg));
+        gpuErrchk(hipMalloc((void **)&dc, sizeof hc));
+        gpuErrchk(hipMalloc((void **)&dS, 3 * nx * nx * Nk * sizeof(T)));
+        gpuErrchk(hipMalloc((void **)&dgam, nx * Nk * sizeof(T)));
+        gpuErrchk(hipMalloc((void **)&dGi, sizeof hG));
+        gpuErrchk(hipMalloc((void **)&dP, 3 * nx * nx * Nk * sizeof(T)));
+        gpuErrchk(hipMalloc((void **)&dl, nx * Nk * sizeof(T)));
+        gpuErrchk(hipMalloc((void **)&dz, sizeof hg));
+        gpuErrchk(hipMalloc((void **)&d_it, sizeof(uint32_t)));
+        gpuErrchk(hipMalloc((void **)&d_fl, 1));
+        gpuErrchk(hipMemcpy(dG, hG, sizeof hG, hipMemcpyHostToDevice));
+        gpuErrchk(hipMemcpy(dC, hC, sizeof hC, hipMemcpyHostToDevice));
+        gpuErrchk(hipMemcpy(dg, hg, sizeof hg, hipMemcpyHostToDevice));
+        gpuErrchk(hipMemcpy(dc, hc, sizeof hc, hipMemcpyHostToDevice));
+        gpuErrchk(hipMemset(dl, 0, nx * Nk * sizeof(T)));
+        pcg_config<T> cfg;
+        cfg.pcg_exit_tol = sizeof(T) == 8 ? T(1e-24) : T(1e-12);
+        cfg.pcg_max_iter = 50;
+        kktStep<T>(nx, nu, Nk, 1, dG, dC, dg, dc, dS, dgam, dGi, dP, dl, dz, d_it, d_fl, &cfg);
+        gpuErrchk(hipDeviceSynchronize());
+        T lam[6], z[8];
+        uint32_t it;
+        gpuErrchk(hipMemcpy(lam, dl, sizeof lam, hipMemcpyDeviceToHost));
+        gpuErrchk(hipMemcpy(z, dz, sizeof z, hipMemcpyDeviceToHost));
+        gpuErrchk(hipMemcpy(&it, d_it, sizeof it, hipMemcpyDeviceToHost));
+        snprintf(tag, sizeof tag, "%s kkt_step", prec);
+        report(tag, it, lam);
+        printf("%s kkt_z=", prec);
+        for (int i = 0; i < 8; ++i) printf("%.17g ", (double)z[i]);
+        printf("\n");
+        // the same through the two separate wrappers, from the lambda just found: the same z, bit for bit
+        T *dz2;
+        gpuErrchk(hipMalloc((void **)&dz2, sizeof hg));
+        formSchur<T>(nx, nu, Nk, 1, dG, dC, dg, dc, dS, dgam, dGi);
+        recoverPrimal<T>(nx, nu, Nk, 1, dGi, dC, dg, dl, dz2);
+        gpuErrchk(hipDeviceSynchronize());
+        T z2[8];
+        gpuErrchk(hipMemcpy(z2, dz2, sizeof z2, hipMemcpyDeviceToHost));
+        bool same = true;
+        for (int i = 0; i < 8; ++i) same = same && z2[i] == z[i];
+        printf("%s kkt_wrappers_agree=%d\n", prec, (int)same);
+        for (void *p : {(void *)dG, (void *)dC, (void *)dg, (void *)dc, (void *)dS, (void *)dgam, (void *)dGi, (void *)dP, (void *)dl,
+                        (void *)dz, (void *)dz2, (void *)d_it, (void *)d_fl})
+            gpuErrchk(hipFree(p));
+    }
 }
 
 int main()

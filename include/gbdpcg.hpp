@@ -253,6 +253,54 @@ uint32_t solvePCG(csr_t<T> *h_S, csr_t<T> *h_Pinv, T *h_gamma, T *h_lambda, unsi
     return iters;
 }
 
+// ---- the steps either side of the solve (no counterpart in the reference tree: README.md:2-11 states the system they produce;
+// layouts and formulas in gbdpcg.h).  Device pointers, packed KKT blocks of `batch` problems; errors end the process like gpuErrchk.
+template <typename T>
+void formSchur(uint32_t stateSize, uint32_t controlSize, uint32_t knotPoints, uint32_t batch, const T *d_G, const T *d_C,
+               const T *d_g, const T *d_c, T *d_S, T *d_gamma, T *d_Ginv, hipStream_t stream = nullptr)
+{
+    static_assert(gbdpcg_detail::is_f32<T> || gbdpcg_detail::is_f64<T>, "formSchur<T>: T is float or double");
+    gbdpcg_handle_t h = gbdpcg_detail::handle();
+    if constexpr (gbdpcg_detail::is_f32<T>) {
+        GBDPCG_CHECK(gbdpcg_form_schur_f32(h, stateSize, controlSize, knotPoints, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, stream), "formSchur");
+    } else {
+        GBDPCG_CHECK(gbdpcg_form_schur_f64(h, stateSize, controlSize, knotPoints, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, stream), "formSchur");
+    }
+}
+
+template <typename T>
+void recoverPrimal(uint32_t stateSize, uint32_t controlSize, uint32_t knotPoints, uint32_t batch, const T *d_Ginv, const T *d_C,
+                   const T *d_g, const T *d_lambda, T *d_z, hipStream_t stream = nullptr)
+{
+    static_assert(gbdpcg_detail::is_f32<T> || gbdpcg_detail::is_f64<T>, "recoverPrimal<T>: T is float or double");
+    gbdpcg_handle_t h = gbdpcg_detail::handle();
+    if constexpr (gbdpcg_detail::is_f32<T>) {
+        GBDPCG_CHECK(gbdpcg_recover_primal_f32(h, stateSize, controlSize, knotPoints, batch, d_Ginv, d_C, d_g, d_lambda, d_z, stream), "recoverPrimal");
+    } else {
+        GBDPCG_CHECK(gbdpcg_recover_primal_f64(h, stateSize, controlSize, knotPoints, batch, d_Ginv, d_C, d_g, d_lambda, d_z, stream), "recoverPrimal");
+    }
+}
+
+// KKT blocks -> S, gamma, G^-1 -> symmetric-stair Phi^-1 -> PCG from the d_lambda found in the buffer -> primal step, one call
+// (asynchronous on `stream`; d_iters / d_max_iter_exit: one entry per problem, on the device).
+template <typename T>
+void kktStep(uint32_t stateSize, uint32_t controlSize, uint32_t knotPoints, uint32_t batch, const T *d_G, const T *d_C, const T *d_g,
+             const T *d_c, T *d_S, T *d_gamma, T *d_Ginv, T *d_Pinv, T *d_lambda, T *d_z, uint32_t *d_iters,
+             uint8_t *d_max_iter_exit, struct pcg_config<T> *config, hipStream_t stream = nullptr)
+{
+    static_assert(gbdpcg_detail::is_f32<T> || gbdpcg_detail::is_f64<T>, "kktStep<T>: T is float or double");
+    gbdpcg_handle_t h = gbdpcg_detail::handle();
+    if constexpr (gbdpcg_detail::is_f32<T>) {
+        GBDPCG_CHECK(gbdpcg_kkt_step_f32(h, stateSize, controlSize, knotPoints, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, d_Pinv,
+                                         GBDPCG_PINV_STAIR, d_lambda, nullptr, nullptr, config->pcg_exit_tol, config->pcg_max_iter,
+                                         d_iters, d_max_iter_exit, d_z, stream), "kktStep");
+    } else {
+        GBDPCG_CHECK(gbdpcg_kkt_step_f64(h, stateSize, controlSize, knotPoints, batch, d_G, d_C, d_g, d_c, d_S, d_gamma, d_Ginv, d_Pinv,
+                                         GBDPCG_PINV_STAIR, d_lambda, nullptr, nullptr, config->pcg_exit_tol, config->pcg_max_iter,
+                                         d_iters, d_max_iter_exit, d_z, stream), "kktStep");
+    }
+}
+
 // ---- the README's spelling (README.md:42): int pcg_solve<T>(cbtd_t *h_S, ...) ---------------------
 template <typename T>
 int pcg_solve(cbtd_t<T> *h_S, T *h_gamma, T *h_lambda, unsigned stateSize, unsigned knotPoints,

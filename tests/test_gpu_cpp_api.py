@@ -78,6 +78,25 @@ def test_selftest_against_oracle(orc):
         assert it in counts and np.linalg.norm(lam - lam_star) / np.linalg.norm(lam_star) < 2e-4
 
 
+def test_selftest_kkt_wrappers():
+    """formSchur<T> / recoverPrimal<T> / kktStep<T> of include/gbdpcg.hpp on the 2-state, 1-control, 3-knot problem written out
+    in examples/api_selftest.cpp: multipliers and primal step against numpy.linalg.solve of the whole KKT system."""
+    from oracle import schur_oracle as so
+    out = run("api_selftest")
+    rec = parse(out)
+    G = [2, 0.5, 0.5, 1, 3, 1.5, 0.2, 0.2, 2, 1, 1, 0, 0, 4]
+    C = [1, 0.1, -0.2, 0.9, 0.5, 1, 0.8, 0, 0.3, 1.1, 0, 0.7]
+    g = [1, -1, 0.5, 0.3, 0.2, -0.4, -0.6, 0.9]
+    c = [0.5, -0.25, 0.1, 0.2, -0.3, 0.05]
+    z_star, lam_star = so.dense_kkt_solve(2, 1, 3, G, C, g, c)
+    for prec, tol in (("f64", 1e-11), ("f32", 2e-5)):
+        it, lam = rec[f"{prec} kkt_step"]
+        assert 1 <= it < 50 and np.linalg.norm(lam - lam_star) < tol * np.linalg.norm(lam_star)
+        z = [np.array([float(v) for v in ln.split("=")[1].split()]) for ln in out.splitlines() if ln.startswith(f"{prec} kkt_z=")][0]
+        assert np.linalg.norm(z - z_star) < tol * np.linalg.norm(z_star)
+        assert f"{prec} kkt_wrappers_agree=1" in out
+
+
 @pytest.mark.parametrize("exe", ["pcg_solve", "pcg_solve_dp"])
 def test_example_drivers_print_like_the_reference(exe):
     """examples/pcg_solve.cu:36-41 prints 'GBD-PCG returned in <res> iters.' then 'Lambda: ' and six values."""
