@@ -238,7 +238,7 @@ template <typename T>
 gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, const T *d_S, const T *d_Pinv,
                          const T *d_gamma, T *d_lambda, T *d_r, T *d_p, T tol, uint32_t max_iter,
                          uint32_t *d_iters, uint8_t *d_exit, hipStream_t stream, bool blocking = false,
-                         uint32_t given_verdict_stride = 0)
+                         uint32_t given_verdict_stride = 0, bool known_symmetric = false)
 {
     if (!h || !d_S || !d_gamma || !d_lambda || !d_iters || !shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
@@ -259,7 +259,12 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
         const bool cluster_only = cluster_members<T>(n, N) != 0 && !resident_sym_shape<T>(n, N);
         const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && !cluster_only &&
                              fused_has_symmetric<T>(h->dev, n, N, batch);
-        if (has_sym && h->symmetric == 2 && given_verdict_stride) {
+        if (has_sym && h->symmetric == 2 && known_symmetric) {
+            // the caller inside this library KNOWS that every problem is symmetric in storage (gbdpcg_kkt_step_*: S written by
+            // form_schur, Pinv by the stair kernel from that S): one launch, no test, no verdict bytes, no general launch
+            a.symmetric = true;
+            HIP_TRY(h, launch_pcg_fused<T>(h->dev, a, stream));
+        } else if (has_sym && h->symmetric == 2 && given_verdict_stride) {
             // the verdict bytes are already in h->sym_flags, put there on this stream by the stair kernel that just
             // formed Pinv from S (gbdpcg_form_pinv_solve_*): no test launch
             a.sel_stride = given_verdict_stride;
@@ -465,8 +470,28 @@ gbdpcg_status kkt_step_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t N, uint32_t
     if (!k.Ginv || !k.z) return GBDPCG_ERR_INVALID;
     gbdpcg_status st = form_schur_impl<T>(h, nx, k.nu, N, batch, k.G, k.C, k.g, k.c, d_S, d_gamma, k.Ginv, stream);
     if (st != GBDPCG_OK) return st;
-    st = form_pinv_solve_impl<T>(h, nx, N, batch, d_S, d_Pinv, kind, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit,
-                                 stream);
+    // form_schur writes S exactly symmetric in storage (R_k and L_{k+1} are copies of the same registers), and where the
+    // one-launch stair kernel forms Pinv from such an S it writes every pair as mirror images: in the default symmetric mode
+    // the verdicts of gbdpcg_form_pinv_solve_* would all read "symmetric", so they are neither written nor read here and the
+    // general-storage launch that would own nothing (11 us of a 0.66 ms step) is not made.  Same kernels on the same numbers:
+    // same results as the three calls.
+    bool known = false;
+    {
+        DEVICE_SCOPE(h);
+        known = d_S && d_Pinv && shape_ok(nx, N, batch) && mappable<T>(nx) && (int)kind >= 0 && (int)kind <= 2 && h->symmetric == 2 &&
+                pick_path<T>(h, nx, N, batch) == GBDPCG_PATH_FUSED && fused_has_symmetric<T>(h->dev, nx, N, batch) &&
+                pinv_verdict_chunks<T>(nx, N, (int)kind) != 0;
+    }
+    if (known) {
+        if (!d_gamma || !d_lambda || !d_iters) return GBDPCG_ERR_INVALID;
+        DEVICE_SCOPE(h);
+        HIP_TRY(h, launch_form_pinv<T>(h->dev, nx, N, batch, d_S, d_Pinv, (int)kind, stream, nullptr));
+        st = solve_impl<T>(h, nx, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit, stream, false,
+                           0, true);
+    } else {
+        st = form_pinv_solve_impl<T>(h, nx, N, batch, d_S, d_Pinv, kind, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit,
+                                     stream);
+    }
     if (st != GBDPCG_OK) return st;
     return recover_primal_impl<T>(h, nx, k.nu, N, batch, k.Ginv, k.C, k.g, d_lambda, k.z, stream);
 }
