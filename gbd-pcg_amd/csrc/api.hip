@@ -9,6 +9,10 @@
 #include "../../include/gbdpcg.h"
 #include "internal.hpp"
 
+#ifndef GBDPCG_KKT_SKIP_L
+#define GBDPCG_KKT_SKIP_L 1   // 0: the stair kernel of gbdpcg_kkt_step_* reads and compares L_{k+1} like everywhere else (A/B runs)
+#endif
+
 using namespace gbdpcg;
 
 struct gbdpcg_context {
@@ -485,7 +489,7 @@ gbdpcg_status kkt_step_impl(gbdpcg_handle_t h, uint32_t nx, uint32_t N, uint32_t
     if (known) {
         if (!d_gamma || !d_lambda || !d_iters) return GBDPCG_ERR_INVALID;
         DEVICE_SCOPE(h);
-        HIP_TRY(h, launch_form_pinv<T>(h->dev, nx, N, batch, d_S, d_Pinv, (int)kind, stream, nullptr));
+        HIP_TRY(h, launch_form_pinv<T>(h->dev, nx, N, batch, d_S, d_Pinv, (int)kind, stream, nullptr, GBDPCG_KKT_SKIP_L != 0));
         st = solve_impl<T>(h, nx, N, batch, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, d_iters, d_exit, stream, false,
                            0, true);
     } else {

@@ -162,7 +162,8 @@ template <typename T> bool fused_has_symmetric(const DeviceInfo &dev, uint32_t n
 // that chunk was exactly symmetric in S and therefore is in Pinv (pcg_takes ANDs them).
 template <typename T>
 hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S,
-                            T *Pinv, int kind, hipStream_t s, uint8_t *verdicts = nullptr);
+                            T *Pinv, int kind, hipStream_t s, uint8_t *verdicts = nullptr, bool s_symmetric = false);
+// (s_symmetric: the caller KNOWS L_{k+1} == R_k^T in S bit for bit -- the one-launch stair kernel then never reads L)
 template <typename T> uint32_t pinv_verdict_chunks(uint32_t n, uint32_t N, int kind);
 
 // ---- schur.hip: KKT blocks -> S, gamma, G^-1;  lambda -> primal step.  Layouts in include/gbdpcg.h.

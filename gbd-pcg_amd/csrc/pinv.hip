@@ -586,7 +586,8 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
 // follows needs no symmetry test of its own (gbdpcg_form_pinv_solve_*).  Written unconditionally.
 template <typename T, int NCT>
 __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t N, uint32_t chunks, const T *__restrict__ S,
-                                                                       T *__restrict__ Pinv, uint8_t *__restrict__ verdicts)
+                                                                       T *__restrict__ Pinv, uint8_t *__restrict__ verdicts,
+                                                                       bool s_symmetric)
 {
     constexpr uint32_t n = NCT, nn = n * n, NP = (n + 3) / 4 * 4, H = n / 2, PAIRS = 15;
     static_assert(n <= 16 && n % 2 == 0, "quarter-wave elimination and 2 x 2 tiles");
@@ -674,20 +675,21 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
             const uint32_t i = lane + 64 * q;
             if (i < nn) {
                 B[i] = S[blk + 2 * (size_t)nn + i];   // R_k(r,c) at c n + r
-                Wt[i] = S[nb + i];                    // L_{k+1}, as stored
+                if (!s_symmetric) Wt[i] = S[nb + i];  // L_{k+1}, as stored (not read at all when the caller knows S symmetric)
             }
         }
         group_sync<64>();
 #pragma unroll
         for (uint32_t q = 0; q < EPL; ++q) {
             const uint32_t i = lane + 64 * q;
-            if (i < nn) {
+            lt[q] = T(0);
+            if (i < nn && !s_symmetric) {
                 const uint32_t c = i / n, r = i - c * n;
                 lt[q] = Wt[r * n + c];                // L_{k+1}(c,r)
                 differs |= pinv_bits(B[i]) != pinv_bits(lt[q]);
             }
         }
-        const bool symmetric = __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
+        const bool symmetric = s_symmetric || __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
         any_asymmetric |= !symmetric;
         group_sync<64>();
         for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
@@ -900,7 +902,7 @@ template <typename T> uint32_t pinv_verdict_chunks(uint32_t n, uint32_t N, int k
 
 template <typename T>
 hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
-                            int kind, hipStream_t s, uint8_t *verdicts)
+                            int kind, hipStream_t s, uint8_t *verdicts, bool s_symmetric)
 {
     if (verdicts && pinv_verdict_chunks<T>(n, N, kind) == 0) return hipErrorInvalidValue;  // caller asks first
     // register-resident tableau for the compile-time block sizes with 2n <= 64 lanes
@@ -914,7 +916,7 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
                 if (chunks) {                                                                                        \
                     if ((uint64_t)chunks * batch > 0x7fffffffull) return hipErrorInvalidValue;                       \
                     hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN>), dim3(chunks * batch), dim3(kPinvThreads), 0, s, N, \
-                                       chunks, S, Pinv, verdicts);                                                   \
+                                       chunks, S, Pinv, verdicts, s_symmetric);                                                   \
                     return hipGetLastError();                                                                        \
                 }                                                                                                    \
             }                                                                                                        \
@@ -970,9 +972,9 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
 }
 
 template hipError_t launch_form_pinv<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const float *,
-                                            float *, int, hipStream_t, uint8_t *);
+                                            float *, int, hipStream_t, uint8_t *, bool);
 template hipError_t launch_form_pinv<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, const double *,
-                                             double *, int, hipStream_t, uint8_t *);
+                                             double *, int, hipStream_t, uint8_t *, bool);
 template uint32_t pinv_verdict_chunks<float>(uint32_t, uint32_t, int);
 template uint32_t pinv_verdict_chunks<double>(uint32_t, uint32_t, int);
 
