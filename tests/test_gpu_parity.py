@@ -710,8 +710,8 @@ def _sweep_cases(count=48, seed=20261004):
     rng = np.random.default_rng(seed)
     cases = []
     for i in range(count):
-        n = int(rng.choice([1, 2, 3, 5, 6, 7, 8, 12, 13, 14, 14, 14, 16, 18, 24, 25, 36, 40]))
-        N = int(rng.choice([1, 2, 3, 9, 31, 64, 72, 73, 100, 128, 129, 200]))
+        n = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 13, 14, 14, 14, 16, 18, 24, 25, 36, 40]))
+        N = int(rng.choice([1, 2, 3, 9, 31, 64, 72, 73, 80, 81, 100, 128, 129, 168, 200, 256]))
         if n * n * N > 400000:
             N = max(1, 400000 // (n * n))
         B = int(rng.choice([1, 2, 3, 5, 9]))
@@ -723,7 +723,7 @@ def _sweep_cases(count=48, seed=20261004):
     # batches beyond the CU count: persistent workgroups, several rounds of the resident kernels, the symmetric
     # streaming kernels (which are only taken from 256 problems on)
     for j in range(max(8, count // 6)):
-        n = int(rng.choice([6, 8, 12, 14, 14, 14, 16]))
+        n = int(rng.choice([4, 6, 8, 12, 14, 14, 14, 16]))
         N = int(rng.choice([5, 20, 64, 73, 100, 128]))
         B = int(rng.integers(256, 700))
         dtype = [np.float32, np.float64][int(rng.integers(2))]
