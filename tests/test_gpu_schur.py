@@ -266,3 +266,27 @@ def test_kkt_step_is_the_three_calls(solver, dtype):
     assert np.linalg.norm(zz - oz) <= 3e-4 * np.linalg.norm(oz)   # exit test |eta| < 1e-8: a sanity bound, not the parity bar
     gr.close()
     assert td == z.dtype
+
+
+def _random_kkt_shapes(count=28, seed=99):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        if rng.integers(2):
+            nx, nu = [(4, 2), (6, 3), (8, 4), (12, 6), (14, 7)][int(rng.integers(5))]      # the four-knot kernels
+        else:
+            nx = int(rng.integers(1, 20))
+            nu = int(rng.integers(1, nx + 3))                                               # the any-size kernels
+        N = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 21, 40, 64, 77]))
+        B = int(rng.choice([1, 2, 3, 17, 120]))
+        if nx * nx * N * B > 600000:
+            B = max(1, 600000 // (nx * nx * N))
+        out.append((nx, nu, N, B, [np.float32, np.float64][int(rng.integers(2))]))
+    return out
+
+
+@pytest.mark.parametrize("nx,nu,N,B,dtype", _random_kkt_shapes(), ids=lambda v: getattr(v, "__name__", str(v)))
+def test_randomized_kkt_shapes(solver, nx, nu, N, B, dtype):
+    """Random block sizes, horizons and batches through both kernel families (fixed seed): S, gamma, G^-1 and the recovered step
+    against the fp64 block formulas, storage symmetry bit for bit."""
+    test_form_schur_and_recover_vs_oracle(solver, nx, nu, N, B, dtype, 2e-4 if dtype == np.float32 else 1e-11)
