@@ -466,7 +466,8 @@ __device__ __forceinline__ void schur_form_quad_body(uint32_t N, uint32_t run, u
     // The write-outs move SW consecutive elements per lane and store (one 16-byte store in fp32: a store instruction costs this
     // kernel ~70 cycles of issue whatever its width -- 54 dword stores per step were a quarter of its time): OUT_T trips for the
     // four S rows of a step, GI_T for the G^-1 of its four knots; ST_I store instructions per trip.
-    constexpr uint32_t SW = GBDPCG_SCHUR_ST4 ? 4 : 1, ST_I = SW * sizeof(T) > 16 ? SW * sizeof(T) / 16 : 1;
+    constexpr uint32_t SW = GBDPCG_SCHUR_ST4 && Q::SROW % 4 == 0 ? 4 : 1;   // (an odd block size: rows of 3 n^2 elements do not split into fours)
+    constexpr uint32_t ST_I = SW * sizeof(T) > 16 ? SW * sizeof(T) / 16 : 1;
     constexpr uint32_t OUT_T = (4 * Q::SROW / SW + 63) / 64, GI_T = (4 * Q::SG / SW + 63) / 64;
     constexpr uint32_t S_STORES = OUT_T * ST_I + 1, GI_STORES = GI_T * ST_I;   // + 1: gamma
     static_assert((4 * Q::SROW) % SW == 0 && Q::SROW % SW == 0 && (4 * Q::SG) % SW == 0, "whole groups");
@@ -947,8 +948,9 @@ static uint32_t waves_for(const DeviceInfo &dev, size_t wave_bytes)
 }
 
 // The block sizes the four-knots-per-wave kernels are built for: stateSize = 2 x joints, controlSize = joints (a manipulator's
-// positions and velocities against its torques; 14 / 7 is the BASELINE shape).  Other sizes take the any-size LDS kernels.
-#define GBDPCG_QUAD_SHAPES(X) X(4, 2) X(6, 3) X(8, 4) X(12, 6) X(14, 7)
+// positions and velocities against its torques; 14 / 7 is the BASELINE shape), and the pendulum (2 / 1), cart-pole (4 / 1) and
+// quadrotor (12 / 4, 13 / 4 with a quaternion) shapes of the MPC literature.  Other sizes take the any-size LDS kernels.
+#define GBDPCG_QUAD_SHAPES(X) X(2, 1) X(4, 1) X(4, 2) X(6, 3) X(8, 4) X(12, 4) X(12, 6) X(13, 4) X(14, 7)
 
 template <typename T, int NX, int NU>
 hipError_t launch_form_quad(const DeviceInfo &dev, uint32_t N, uint32_t batch, const T *G, const T *C, const T *g, const T *c, T *S,

@@ -102,14 +102,14 @@ def test_four_knot_form_runs_of_every_length(solver, N, B):
         test_form_schur_and_recover_vs_oracle(solver, 14, 7, N, B, dtype, tol)
 
 
-QUAD_SHAPES = [(4, 2), (6, 3), (8, 4), (12, 6), (14, 7)]   # GBDPCG_QUAD_SHAPES of csrc/schur.hip
+QUAD_SHAPES = [(2, 1), (4, 1), (4, 2), (6, 3), (8, 4), (12, 4), (12, 6), (13, 4), (14, 7)]   # GBDPCG_QUAD_SHAPES of csrc/schur.hip
 
 
 @pytest.mark.parametrize("nx,nu", QUAD_SHAPES[:-1])
 @pytest.mark.parametrize("N,B", [(1, 2), (3, 1), (4, 5), (16, 3), (50, 2), (64, 33), (128, 1), (7, 400)])
 def test_four_knot_kernels_of_the_other_block_sizes(solver, monkeypatch, nx, nu, N, B):
     """The four-knots-per-wave formation kernel and the register recovery kernel are built for stateSize = 2 x controlSize in
-    {4, 6, 8, 12, 14}: every size against the oracle (fp32 and fp64; whole runs, split runs, horizons that are not a multiple of
+    {4, 6, 8, 12, 14} and for the 2/1, 4/1, 12/4, 13/4 shapes: every size against the oracle (fp32 and fp64; whole runs, split runs, horizons that are not a multiple of
     4), the recovery bit for bit against the any-size kernel, and nothing written behind the outputs."""
     for dtype, tol in ((np.float32, 2e-4), (np.float64, 1e-11)):
         test_form_schur_and_recover_vs_oracle(solver, nx, nu, N, B, dtype, tol)
@@ -273,7 +273,7 @@ def _random_kkt_shapes(count=28, seed=99):
     out = []
     for _ in range(count):
         if rng.integers(2):
-            nx, nu = [(4, 2), (6, 3), (8, 4), (12, 6), (14, 7)][int(rng.integers(5))]      # the four-knot kernels
+            nx, nu = QUAD_SHAPES[int(rng.integers(len(QUAD_SHAPES)))]                       # the four-knot kernels
         else:
             nx = int(rng.integers(1, 20))
             nu = int(rng.integers(1, nx + 3))                                               # the any-size kernels
