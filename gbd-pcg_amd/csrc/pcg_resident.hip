@@ -180,12 +180,12 @@ __global__ __launch_bounds__(512) GBDPCG_RES_OCC_ATTR void pcg_resident_kernel(P
 // Taken whenever the shape fits: the matrices are then read once per solve instead of once per iteration.  Built for the even
 // block sizes below (fp32: two rows per lane; fp64: one row per lane, not for n = 14 -- 168 matrix VGPRs plus the fp64 working
 // set spill): n = 14 is BASELINE config 2 (N <= 72); the smaller blocks (stateSize of 2-6 joint arms) fit longer horizons
-// (n = 8: N <= 128, n = 4: N <= 256 in fp32) and leave room for several workgroups per compute unit.
+// (n = 8: N <= 128, n = 10: N <= 96, n = 4: N <= 256 in fp32) and leave room for several workgroups per compute unit.
 // GBDPCG_NO_RESIDENT disables the path (tuning runs).
 // (n = 2 works too -- 857 -> 52 us per 1024 converged solves of N = 128 -- but is left to the streaming kernel: on the reference's own
 // example system (n = 2, N = 3, kappa ~ 1562, fp32) this kernel's summation order meets the exit test one iteration before the oracle's,
 // and that system is where equal iteration counts are asserted.)
-#define GBDPCG_RESIDENT_N(X) X(4) X(6) X(8) X(12) X(14)
+#define GBDPCG_RESIDENT_N(X) X(4) X(6) X(8) X(10) X(12) X(14)
 
 template <typename T> bool resident_shape(uint32_t n, uint32_t N)
 {
