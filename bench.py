@@ -507,11 +507,18 @@ def run_rank(args, world, rank, local_rank):
     del S, P, gamma, lam, r, p
     torch.cuda.empty_cache()
 
+    # The blocks behind the headline must not cost the line: a failure in one of them is reported in its place.
+    def guarded(key, fn, *a):
+        try:
+            out[key] = fn(*a)
+        except Exception as e:   # noqa: BLE001 -- reported, not swallowed: the key carries the error
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+
     if world == 1 and not args.no_configs:
-        out["configs"] = bench_configs(solver, torch, binding, synth, dev, stream)
-        out["mpc_step"] = bench_mpc_step(solver, torch, binding, synth, dev, stream)
+        guarded("configs", bench_configs, solver, torch, binding, synth, dev, stream)
+        guarded("mpc_step", bench_mpc_step, solver, torch, binding, synth, dev, stream)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n, N, iters)
+        guarded("cpu_baseline", cpu_baseline, n, N, iters)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -234,3 +234,8 @@ def test_bench_line_contract():
     assert rec["configs"]["C4"]["iters_converged"] == 10.0 and rec["configs"]["C2"]["iters_converged"] == 9.0
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    ms = rec["mpc_step"]   # the steps either side of the solve at the headline batch shape
+    assert "error" not in ms and ms["S_symmetric_in_storage"] is True and ms["all_converged_and_finite"] is True
+    for k in ("form_schur", "recover_primal"):
+        assert ms[k]["bound"] == "hbm" and 0.1 < ms[k]["frac"] <= 1.0 and abs(ms[k]["frac"] - ms[k]["achieved"] / ms[k]["peak"]) < 1e-12
+    assert ms["us_per_step_of_1024_problems"] < ms["form_schur"]["us"] + ms["form_pinv_solve"]["us"] + ms["recover_primal"]["us"] + 50.0
