@@ -430,78 +430,82 @@ def run_rank(args, world, rank, local_rank):
         }
 
     if world == 1:
-        # General (not bit-symmetric) storage: gbdpcg_set_symmetric(0) makes every problem take the path a caller-formed
-        # Phi^-1 takes.  Since round 2 that is the cluster kernel (both matrices register-resident over two CUs per
-        # problem, two cross-CU hand-offs per iteration); the kernel that streams both matrices every iteration is timed in
-        # a child process with GBDPCG_NO_CLUSTER=1 (the switch is read once per process).
-        gen_ms, gen_best = time_mode(0, 60)
-        gen_tflops = flops / (gen_ms * 1e-3) / 1e12
-        full_bytes = B * (2 * 3 * N * n * n + 5 * n * N) * 4      # [L|D|R] of both matrices once per solve + vectors
-        clusters = 256 // 2
-        rounds = -(-B // clusters)
-        out["general_kernel"] = {
-            "kernel": "pcg_cluster_kernel<14,2,true> (gbdpcg_set_symmetric(0): general storage, two CUs per problem)",
-            "bound": "latency", "achieved": gen_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": gen_tflops / FP32_VECTOR_PEAK_TFLOPS, "kernel_ms": gen_ms, "kernel_ms_min": gen_best,
-            "traffic": pmc_traffic("pcg_cluster_kernel"),
-            "problem_iters_per_sec_one_gpu": B * iters / (gen_ms * 1e-3),
-            "us_per_iteration_of_a_cluster": gen_ms * 1e3 / rounds / (iters + 1),
-            "handoff_floor_us_per_iteration": 2 * 0.5,
-            "hbm_share": {"bytes_moved_per_launch": full_bytes, "achieved_GBps": full_bytes / (gen_ms * 1e-3) / 1e9,
-                          "frac_of_hbm_peak": full_bytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-            "streaming_kernel": time_streaming_general(n, N, B, iters),
-            "note": "the matrices are read once per solve; an iteration is two products (LDS-read bound) and two hand-offs "
-                    "between the two workgroups of a problem (0.44-0.56 us each, tools/hop_probe.hip): the bound is that "
-                    "latency, not HBM and not the VALU; us_per_iteration_of_a_cluster includes the tile loads (upper bound)"}
+        try:
+            # General (not bit-symmetric) storage: gbdpcg_set_symmetric(0) makes every problem take the path a caller-formed
+            # Phi^-1 takes.  Since round 2 that is the cluster kernel (both matrices register-resident over two CUs per
+            # problem, two cross-CU hand-offs per iteration); the kernel that streams both matrices every iteration is timed in
+            # a child process with GBDPCG_NO_CLUSTER=1 (the switch is read once per process).
+            gen_ms, gen_best = time_mode(0, 60)
+            gen_tflops = flops / (gen_ms * 1e-3) / 1e12
+            full_bytes = B * (2 * 3 * N * n * n + 5 * n * N) * 4      # [L|D|R] of both matrices once per solve + vectors
+            clusters = 256 // 2
+            rounds = -(-B // clusters)
+            out["general_kernel"] = {
+                "kernel": "pcg_cluster_kernel<14,2,true> (gbdpcg_set_symmetric(0): general storage, two CUs per problem)",
+                "bound": "latency", "achieved": gen_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": gen_tflops / FP32_VECTOR_PEAK_TFLOPS, "kernel_ms": gen_ms, "kernel_ms_min": gen_best,
+                "traffic": pmc_traffic("pcg_cluster_kernel"),
+                "problem_iters_per_sec_one_gpu": B * iters / (gen_ms * 1e-3),
+                "us_per_iteration_of_a_cluster": gen_ms * 1e3 / rounds / (iters + 1),
+                "handoff_floor_us_per_iteration": 2 * 0.5,
+                "hbm_share": {"bytes_moved_per_launch": full_bytes, "achieved_GBps": full_bytes / (gen_ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": full_bytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "streaming_kernel": time_streaming_general(n, N, B, iters),
+                "note": "the matrices are read once per solve; an iteration is two products (LDS-read bound) and two hand-offs "
+                        "between the two workgroups of a problem (0.44-0.56 us each, tools/hop_probe.hip): the bound is that "
+                        "latency, not HBM and not the VALU; us_per_iteration_of_a_cluster includes the tile loads (upper bound)"}
 
-        # standalone SpMV over FOUR distinct 308 MB matrices in rotation (1.23 GB: the 256 MiB Infinity Cache
-        # cannot hold anything between two uses of the same line), each launch bracketed by its own event pair
-        mats = [S, P, S.clone(), P.clone()]
-        x = torch.randn_like(gamma)
-        y = torch.empty_like(gamma)
+            # standalone SpMV over FOUR distinct 308 MB matrices in rotation (1.23 GB: the 256 MiB Infinity Cache
+            # cannot hold anything between two uses of the same line), each launch bracketed by its own event pair
+            mats = [S, P, S.clone(), P.clone()]
+            x = torch.randn_like(gamma)
+            y = torch.empty_like(gamma)
 
-        def time_spmv(launches=104, rounds=3):
-            res = []
-            for _ in range(rounds):
-                evs = new_events(launches)
-                torch.cuda.synchronize()
-                for k, (e0, e1) in enumerate(evs):
-                    e0.record(stream)
-                    solver.spmv(n, N, B, mats[k % 4], x, y)
-                    e1.record(stream)
-                torch.cuda.synchronize()
-                res.append(median([e0.elapsed_time(e1) for e0, e1 in evs[4:]]))
-            return median(res)
+            def time_spmv(launches=104, rounds=3):
+                res = []
+                for _ in range(rounds):
+                    evs = new_events(launches)
+                    torch.cuda.synchronize()
+                    for k, (e0, e1) in enumerate(evs):
+                        e0.record(stream)
+                        solver.spmv(n, N, B, mats[k % 4], x, y)
+                        e1.record(stream)
+                    torch.cuda.synchronize()
+                    res.append(median([e0.elapsed_time(e1) for e0, e1 in evs[4:]]))
+                return median(res)
 
-        sp_bytes = spmv_bytes_per_launch(n, N, B, 4)
-        sp_ms = time_spmv()
-        sp_gbps = sp_bytes / (sp_ms * 1e-3) / 1e9
-        # the same kernel when consecutive launches alternate between only two matrices (616 MB): what the
-        # Infinity Cache adds
-        mats2 = mats
-        mats = [S, P, S, P]
-        sp2_ms = time_spmv()
-        mats = mats2
-        solver.set_symmetric(1)   # only [D|R] is read (caller's word: a device check would cost as much as the product)
-        sps_ms = time_spmv()
-        solver.set_symmetric(2)
-        del mats, mats2
-        out["spmv_GBps"] = sp_gbps
-        out["spmv"] = {"bound": "hbm", "kernel": "spmv_kernel<float,14,2,4>", "achieved": sp_gbps,
-                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sp_gbps / HBM_PEAK_GBPS,
-                       "frac_of_copy_ceiling": sp_gbps / HBM_COPY_CEIL_GBPS,
-                       "frac_of_cold_read_ceiling": sp_gbps / HBM_COLD_READ_GBPS,
-                       "traffic": pmc_traffic("spmv_kernel<float,14"),
-                       "algorithmic_bytes_per_launch": sp_bytes, "kernel_ms": sp_ms, "statistic": "median of 100 launches x 3 rounds",
-                       "rotation": "4 matrices x 308 MB = 1.23 GB (Infinity Cache cannot serve it)",
-                       "two_matrix_rotation": {"kernel_ms": sp2_ms, "GBps": sp_bytes / (sp2_ms * 1e-3) / 1e9,
-                                               "note": "616 MB rotation, as in round 1: includes Infinity-Cache hits"}}
-        out["spmv_symmetric"] = {"kernel": "spmv_sym_kernel<float,14,4> (gbdpcg_set_symmetric(1): reads [D|R] only)",
-                                 "achieved": sp_bytes / (sps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                 "frac": sp_bytes / (sps_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 "traffic": pmc_traffic("spmv_sym_kernel<float,14"), "kernel_ms": sps_ms,
-                                 "bytes_streamed_per_launch": B * ((2 * N - 1) * n * n + 2 * n * N) * 4,
-                                 "frac_streamed": B * ((2 * N - 1) * n * n + 2 * n * N) * 4 / (sps_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            sp_bytes = spmv_bytes_per_launch(n, N, B, 4)
+            sp_ms = time_spmv()
+            sp_gbps = sp_bytes / (sp_ms * 1e-3) / 1e9
+            # the same kernel when consecutive launches alternate between only two matrices (616 MB): what the
+            # Infinity Cache adds
+            mats2 = mats
+            mats = [S, P, S, P]
+            sp2_ms = time_spmv()
+            mats = mats2
+            solver.set_symmetric(1)   # only [D|R] is read (caller's word: a device check would cost as much as the product)
+            sps_ms = time_spmv()
+            solver.set_symmetric(2)
+            del mats, mats2
+            out["spmv_GBps"] = sp_gbps
+            out["spmv"] = {"bound": "hbm", "kernel": "spmv_kernel<float,14,2,4>", "achieved": sp_gbps,
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sp_gbps / HBM_PEAK_GBPS,
+                           "frac_of_copy_ceiling": sp_gbps / HBM_COPY_CEIL_GBPS,
+                           "frac_of_cold_read_ceiling": sp_gbps / HBM_COLD_READ_GBPS,
+                           "traffic": pmc_traffic("spmv_kernel<float,14"),
+                           "algorithmic_bytes_per_launch": sp_bytes, "kernel_ms": sp_ms, "statistic": "median of 100 launches x 3 rounds",
+                           "rotation": "4 matrices x 308 MB = 1.23 GB (Infinity Cache cannot serve it)",
+                           "two_matrix_rotation": {"kernel_ms": sp2_ms, "GBps": sp_bytes / (sp2_ms * 1e-3) / 1e9,
+                                                   "note": "616 MB rotation, as in round 1: includes Infinity-Cache hits"}}
+            out["spmv_symmetric"] = {"kernel": "spmv_sym_kernel<float,14,4> (gbdpcg_set_symmetric(1): reads [D|R] only)",
+                                     "achieved": sp_bytes / (sps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": sp_bytes / (sps_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                     "traffic": pmc_traffic("spmv_sym_kernel<float,14"), "kernel_ms": sps_ms,
+                                     "bytes_streamed_per_launch": B * ((2 * N - 1) * n * n + 2 * n * N) * 4,
+                                     "frac_streamed": B * ((2 * N - 1) * n * n + 2 * n * N) * 4 / (sps_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        except Exception as e:   # noqa: BLE001 -- the headline above is already measured: report, do not lose the line
+            out["secondary_blocks_error"] = f"{type(e).__name__}: {e}"
+            solver.set_symmetric(2)
 
     graph.close()
     del S, P, gamma, lam, r, p
