@@ -100,7 +100,7 @@ def main():
         with open(os.path.join(dst, f"{rnd}_schur.txt"), "w") as f:
             f.write("# gbd-pcg_amd/tools/schur_run.py on one MI355X: KKT blocks -> S, gamma, G^-1 (form_schur), stair Pinv, converged solve, lambda -> z\n"
                     "# (recover_primal); event-timed medians, GB/s = every input once + every output once / time.  Shapes: the headline batch,\n"
-                    "# a horizon that is not a multiple of 4, fp64, block sizes without a four-knot kernel (the LDS kernels), then the phase stamps\n"
+                    "# a horizon that is not a multiple of 4, fp64, the quadrotor block sizes (12 / 4), block sizes without a four-knot kernel (9 / 3: the LDS kernels), then the phase stamps\n"
                     "# of one step of the four-knot formation kernel (shader cycles; diagnostic build).\n")
             f.write(open(st).read())
     # the kernels of one whole inner step (examples/kkt_step_loop under rocprofv3 --kernel-trace --stats)

@@ -53,6 +53,7 @@ echo "[11] the steps either side of the solve (schur.hip): stage times, kernel s
   python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 40 --N 50 --batch 2048
   python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 20 --dtype f64
   python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 20 --nx 12 --nu 4
+  python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 20 --nx 9 --nu 3
   if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_schurstamps.so ]; then
     GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_schurstamps.so python3 $ROOT/gbd-pcg_amd/tools/schur_run.py --reps 5 --stamps
   fi
