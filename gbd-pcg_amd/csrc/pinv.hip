@@ -584,11 +584,13 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
 // verdicts (optional): one byte per workgroup, 1 when every pair of the chunk had L_{k+1} == R_k^T bit for bit
 // in S -- the pairs of Pinv were then written as mirror images, so the same holds for Pinv and a solve that
 // follows needs no symmetry test of its own (gbdpcg_form_pinv_solve_*).  Written unconditionally.
-template <typename T, int NCT>
+// S_SYM: the caller KNOWS L_{k+1} == R_k^T in S (gbdpcg_kkt_step_*): L is never read.  A compile-time switch: as a kernel argument
+// the same test cost the ordinary path 40 us of 150 (the compiler's schedule of the pair loop changed).
+template <typename T, int NCT, bool S_SYM>
 __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t N, uint32_t chunks, const T *__restrict__ S,
-                                                                       T *__restrict__ Pinv, uint8_t *__restrict__ verdicts,
-                                                                       bool s_symmetric)
+                                                                       T *__restrict__ Pinv, uint8_t *__restrict__ verdicts)
 {
+    constexpr bool s_symmetric = S_SYM;
     constexpr uint32_t n = NCT, nn = n * n, NP = (n + 3) / 4 * 4, H = n / 2, PAIRS = 15;
     static_assert(n <= 16 && n % 2 == 0, "quarter-wave elimination and 2 x 2 tiles");
     using P2 = typename VecOf<T, 2>::type;
@@ -915,8 +917,12 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
                 const uint32_t chunks = pinv_verdict_chunks<T>(n, N, kind);                                          \
                 if (chunks) {                                                                                        \
                     if ((uint64_t)chunks * batch > 0x7fffffffull) return hipErrorInvalidValue;                       \
-                    hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN>), dim3(chunks * batch), dim3(kPinvThreads), 0, s, N, \
-                                       chunks, S, Pinv, verdicts, s_symmetric);                                                   \
+                    if (s_symmetric)                                                                                     \
+                        hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN, true>), dim3(chunks * batch), dim3(kPinvThreads), 0,  \
+                                           s, N, chunks, S, Pinv, verdicts);                                             \
+                    else                                                                                                 \
+                        hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN, false>), dim3(chunks * batch), dim3(kPinvThreads), 0, \
+                                           s, N, chunks, S, Pinv, verdicts);                                                   \
                     return hipGetLastError();                                                                        \
                 }                                                                                                    \
             }                                                                                                        \
