@@ -196,23 +196,29 @@ def free_port():
 
 def launch_ranks(n_ranks):
     """Start n_ranks fresh child processes of this script, one per GPU, and relay rank 0's output.  The parent
-    makes no GPU call (it never imports torch): every rank initialises its own device in its own process."""
+    makes no GPU call (it never imports torch): every rank initialises its own device in its own process.  Every
+    rank's stderr is kept and, if the job fails, its tail is forwarded, so that a first run on a real multi-GPU node
+    that dies says which rank died of what."""
     import tempfile
     port = free_port()
-    procs = []
+    procs, errs = [], []
     with tempfile.TemporaryFile() as out0:
         for rank in range(n_ranks):
             env = dict(os.environ)
             env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(n_ranks),
                         "LOCAL_WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                         "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+            errs.append(tempfile.TemporaryFile())
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=out0 if rank == 0 else subprocess.DEVNULL))
+                                          stdout=out0 if rank == 0 else subprocess.DEVNULL, stderr=errs[-1]))
         # wait for all ranks; a rank that dies takes the job down (the others would sit in the rendezvous or a barrier)
-        failed = False
+        failed, first_dead = False, None
         while any(p.poll() is None for p in procs):
-            if any(p.returncode not in (None, 0) for p in procs):
+            dead = [i for i, p in enumerate(procs) if p.returncode not in (None, 0)]
+            if dead:
                 failed = True
+                if first_dead is None and len(dead) == 1:
+                    first_dead = dead[0]          # seen dead while every other rank was still running
                 for p in procs:
                     if p.poll() is None:
                         p.kill()              # exactly the children started above, by PID
@@ -221,7 +227,18 @@ def launch_ranks(n_ranks):
         out0.seek(0)
         sys.stdout.write(out0.read().decode())
         sys.stdout.flush()
-    if failed or any(codes):
+        failed = failed or any(codes)
+        for rank, f in enumerate(errs):
+            f.seek(0)
+            text = f.read().decode(errors="replace")
+            f.close()
+            if failed and text.strip():
+                mark = " (first to die)" if rank == first_dead else ""
+                sys.stderr.write(f"---- bench.py rank {rank}, exit code {codes[rank]}{mark}: last lines of stderr ----\n")
+                sys.stderr.write(text[-3000:].rstrip() + "\n")
+            elif text.strip():
+                sys.stderr.write(text)       # warnings of a healthy run pass through
+    if failed:
         sys.stderr.write(f"bench.py launcher: rank exit codes {codes}\n")
         sys.exit(1)
 
@@ -239,6 +256,8 @@ def run_dry(args, world, rank):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if os.environ.get("GBDPCG_BENCH_DRY_FAIL_RANK") == str(rank):    # tests/test_distributed.py: what the launcher reports
+        raise RuntimeError(f"injected failure on rank {rank} (dry run)")
     total = BATCH_PER_GPU * world
     lo, hi = sharding.shard_range(total, rank, world)
     spans = [None] * world
@@ -261,6 +280,39 @@ def run_dry(args, world, rank):
 def median(xs):
     s = sorted(xs)
     return s[len(s) // 2]
+
+
+# Bounds on the true residual ||gamma - S lambda|| / ||gamma|| of a timed buffer (asserted, outside the timed region):
+# fixed-count runs sit on the rounding floor of their precision (kappa(S) ~ 27: measured 5e-7 in fp32, 1.4e-13 in fp64 at n = 36, N = 256);
+# runs to exit_tol = 1e-6 stop on |r.Pinv r| < 1e-6 (pcg.cuh:195), an ABSOLUTE test: ||r|| <~ 1e-3 against ||gamma|| ~ 40.
+RESIDUAL_BOUND = {("f32", "fixed"): 2e-6, ("f64", "fixed"): 1e-12, ("f32", "converged"): 1e-3, ("f64", "converged"): 1e-3}
+
+
+def verify_solve(solver, torch, n, N, B, S, gamma, lam, it, fl, kind, fixed_iters=None):
+    """What the timed replays left in their buffers, checked through the library's own SpMV (general kernel: reads L, D
+    and R): true residual of EVERY problem, iteration counts and exit flags.  Raises if the timed work was not a solve."""
+    y = solver.spmv(n, N, B, S, lam)
+    torch.cuda.synchronize()
+    g = gamma.double().reshape(B, -1)
+    res = ((g - y.double().reshape(B, -1)).norm(dim=1) / g.norm(dim=1))
+    dt = "f32" if gamma.dtype == torch.float32 else "f64"
+    # a fixed count too short to converge (the 5-iteration runs that price one iteration) has no residual to promise
+    bound = RESIDUAL_BOUND[(dt, kind)] if kind != "fixed" or fixed_iters >= MAX_ITER else float("inf")
+    itc, flc = it.to(torch.int64) & 0xffffffff, fl.to(torch.int64)
+    rec = {"true_residual_max": float(res.max()), "true_residual_median": float(res.median()), "bound": bound,
+           "problems": B, "iters_min": int(itc.min()), "iters_max": int(itc.max()),
+           "max_iter_exit_values": sorted(int(v) for v in torch.unique(flc).cpu()),
+           "finite": bool(torch.isfinite(lam).all()),
+           "definition": "max over all problems of ||gamma - S lambda|| / ||gamma|| on the buffers the timed replays left, "
+                         "S applied by gbdpcg_spmv (general kernel)"}
+    ok = rec["finite"] and rec["true_residual_max"] < bound
+    if kind == "fixed":      # exit_tol = 0: every problem runs out of iterations (pcg.cuh:195,212)
+        ok = ok and rec["iters_min"] == rec["iters_max"] == fixed_iters and rec["max_iter_exit_values"] == [1]
+    else:                    # to tolerance: every problem converged before max_iter
+        ok = ok and rec["iters_min"] >= 1 and rec["max_iter_exit_values"] == [0]
+    rec["ok"] = bool(ok)
+    assert ok, f"timed buffers do not hold a solve: {rec}"
+    return rec
 
 
 def run_rank(args, world, rank, local_rank):
@@ -333,8 +385,7 @@ def run_rank(args, world, rank, local_rank):
     elapsed = time.perf_counter() - t0
     # RCCL over xGMI: throughput aggregation only (max elapsed, total problem-iterations)
     elapsed, total_units = sharding.aggregate(elapsed, float(B * iters * args.steps), device=agg_device)
-    assert int(it_out.min()) == iters and int(it_out.max()) == iters
-    assert torch.isfinite(lam).all()
+    verified = verify_solve(solver, torch, n, N, B, S, gamma, lam, it_out, fl_out, "fixed", iters)   # outside the timed region
     step_ms = median([a.elapsed_time(b) for a, b in events])   # check kernel + both PCG launches of one replay
 
     def time_graph(gr, reps, warm=5, reset=None):
@@ -359,14 +410,14 @@ def run_rank(args, world, rank, local_rank):
         gr = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, 0.0, iters, it_out, fl_out)
         solver.set_symmetric(2)
         med, best = time_graph(gr, reps)
-        assert torch.isfinite(lam).all() and int(it_out.min()) == iters
+        ver = verify_solve(solver, torch, n, N, B, S, gamma, lam, it_out, fl_out, "fixed", iters)
         gr.close()
-        return med, best
+        return med, best, ver
 
     all_symmetric = (int(solver.check_symmetric(n, N, B, S).min()) == 1
                      and int(solver.check_symmetric(n, N, B, P).min()) == 1)
     REPS = max(100, args.steps)
-    sym_ms, sym_best = time_mode(1, REPS)   # the dominant kernel alone (caller asserts symmetry: no check launch)
+    sym_ms, sym_best, sym_ver = time_mode(1, REPS)   # the dominant kernel alone (caller asserts symmetry: no check launch)
     flops = pcg_flops_per_launch(n, N, B, iters)
     pcg_bytes = pcg_bytes_per_launch(n, N, B, iters, 4)
     resident_bytes = B * (2 * (2 * N - 1) * n * n + 5 * n * N) * 4   # [D|R] of both matrices once per solve + vectors
@@ -383,6 +434,8 @@ def run_rank(args, world, rank, local_rank):
             "value": total_units / elapsed,
             "unit": "iter/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if distributed else 1,
+            "collective_backend": (dist.get_backend() if distributed else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -402,6 +455,7 @@ def run_rank(args, world, rank, local_rank):
                        "sharding": f"problems [g*{BATCH_PER_GPU}, (g+1)*{BATCH_PER_GPU}) on rank g of {world}, seeds 1234+i, "
                                    "no data-path collective; RCCL all_reduce of (max elapsed, sum units) only"},
             "solves_per_sec": total_batch * args.steps / elapsed,
+            "verified": verified,
             "value_definition": "problem-iterations per second (25 PCG iterations x 1024 problems per GPU per step), default path",
             "roofline": {
                 "bound": "valu",
@@ -421,6 +475,7 @@ def run_rank(args, world, rank, local_rank):
                                            "note": "SURVEY 8d bytes (S and Pinv in full, once per iteration) / kernel time: "
                                                    "what a streaming kernel would have to sustain to match; not an HBM rate"},
                 "all_problems_symmetric": all_symmetric,
+                "verified": sym_ver,
                 "note": "peak = fp32 vector peak (= dense fp32 MFMA peak) of MI355X_MICROARCH.md; the matrices are read once "
                         "per solve, so the kernel is bound by VALU issue and on-chip latency, not by HBM"},
             "pinv_onchip": {"hit_rate": iters / (iters + 1.0), "from_lds": lds_share, "from_registers": 1.0 - lds_share,
@@ -435,7 +490,7 @@ def run_rank(args, world, rank, local_rank):
             # Phi^-1 takes.  Since round 2 that is the cluster kernel (both matrices register-resident over two CUs per
             # problem, two cross-CU hand-offs per iteration); the kernel that streams both matrices every iteration is timed in
             # a child process with GBDPCG_NO_CLUSTER=1 (the switch is read once per process).
-            gen_ms, gen_best = time_mode(0, 60)
+            gen_ms, gen_best, gen_ver = time_mode(0, 60)
             gen_tflops = flops / (gen_ms * 1e-3) / 1e12
             full_bytes = B * (2 * 3 * N * n * n + 5 * n * N) * 4      # [L|D|R] of both matrices once per solve + vectors
             clusters = 256 // 2
@@ -451,6 +506,7 @@ def run_rank(args, world, rank, local_rank):
                 "hbm_share": {"bytes_moved_per_launch": full_bytes, "achieved_GBps": full_bytes / (gen_ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": full_bytes / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 "streaming_kernel": time_streaming_general(n, N, B, iters),
+                "verified": gen_ver,
                 "note": "the matrices are read once per solve; an iteration is two products (LDS-read bound) and two hand-offs "
                         "between the two workgroups of a problem (0.44-0.56 us each, tools/hop_probe.hip): the bound is that "
                         "latency, not HBM and not the VALU; us_per_iteration_of_a_cluster includes the tile loads (upper bound)"}
@@ -555,7 +611,7 @@ def bench_configs(solver, torch, binding, synth, dev, stream):
         rec = {"stateSize": n, "knotPoints": N, "batch": B, "dtype": "f32" if es == 4 else "f64",
                "path": {binding.PATH_FUSED: "fused", binding.PATH_SPLIT: "split",
                         binding.PATH_PERSISTENT: "persistent"}.get(solver.choose_path(es, n, N, B), "auto")}
-        times = {}
+        times, vers = {}, {}
         for tag, tol, mi in (("fixed5", 0.0, 5), ("fixed25", 0.0, MAX_ITER), ("converged", 1e-6, MAX_ITER)):
             gr = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, tol, mi, it, fl)
             it.fill_(-1)
@@ -570,7 +626,7 @@ def bench_configs(solver, torch, binding, synth, dev, stream):
                 gr.launch(stream)
                 e1.record(stream)
             torch.cuda.synchronize()
-            assert int(it.min()) >= 1 and bool(torch.isfinite(lam).all()), "the timed replays did not solve anything"
+            vers[tag] = verify_solve(solver, torch, n, N, B, S, gamma, lam, it, fl, "fixed" if tol == 0.0 else "converged", mi)
             times[tag] = (median([a.elapsed_time(b) for a, b in evs]) * 1e3, float(it.float().mean()))
             gr.close()
         (t5, i5), (t25, i25), (tc, ic) = times["fixed5"], times["fixed25"], times["converged"]
@@ -582,7 +638,8 @@ def bench_configs(solver, torch, binding, synth, dev, stream):
                     "us_per_iteration_fixed25_incl_launch": t25 / i25,
                     "problem_iters_per_sec": B * i25 / (t25 * 1e-6),
                     "hbm_floor_us_per_iteration": floor_us, "frac_of_hbm_floor": floor_us / us_iter,
-                    "statistic": f"median of {reps} graph replays; us_per_iteration = (fixed25 - fixed5) / 20"})
+                    "statistic": f"median of {reps} graph replays; us_per_iteration = (fixed25 - fixed5) / 20",
+                    "verified": {k: vers[k] for k in ("fixed25", "converged")}})
         if rec["path"] == "persistent":
             rec["bound"] = ("cross-CU latency: one launch, block-rows register-resident on 128 CUs, two in-kernel all-gathers of "
                             "{partial inner product, boundary knots} per iteration; no matrix byte moves after the first touch, "
@@ -646,6 +703,7 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
     t_form, t_solve, t_rec, t_all = timed(form), timed(solve), timed(recover), timed(chain)
     sym = bool(solver.check_symmetric(nx, N, B, S).all())
     ok = int(fl.sum()) == 0 and bool(torch.isfinite(z).all())
+    ver = verify_solve(solver, torch, nx, N, B, S, gamma, lam, it, fl, "converged")   # the last replay of the whole step
     by_form = (2 * G.numel() + C.numel() + g.numel() + c.numel() + S.numel() + gamma.numel()) * 4
     by_rec = (Ginv.numel() + C.numel() + g.numel() + lam.numel() + z.numel()) * 4
     res = {"shape": {"stateSize": nx, "controlSize": nu, "knotPoints": N, "batch": B, "dtype": "f32"},
@@ -659,7 +717,7 @@ def bench_mpc_step(solver, torch, binding, synth, dev, stream, nu=7, reps=30):
                               "algorithmic_bytes": by_rec, "achieved": by_rec / t_rec / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": by_rec / t_rec / 1e3 / HBM_PEAK_GBPS, "traffic": schur_traffic("schur_recover_quad_kernel")},
            "us_per_step_of_1024_problems": t_all, "kkt_systems_per_sec": B / (t_all * 1e-6),
-           "S_symmetric_in_storage": sym, "all_converged_and_finite": ok,
+           "S_symmetric_in_storage": sym, "all_converged_and_finite": ok, "verified": ver,
            "statistic": f"median of {reps} event-timed repetitions per stage, and of the whole step replayed as one hipGraph "
                         "(gbdpcg_graph_create_kkt_step, lambda reset to 0 before each replay)"}
     gr.close()

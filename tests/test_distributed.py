@@ -106,6 +106,11 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          capture_output=True, text=True, timeout=60, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+    # a rank that dies takes the job down, and the launcher says which rank died of what (its stderr tail)
+    dead = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                          capture_output=True, text=True, timeout=120, env=dict(env, GBDPCG_BENCH_DRY_FAIL_RANK="1"))
+    assert dead.returncode != 0
+    assert "bench.py rank 1, exit code 1" in dead.stderr and "injected failure on rank 1" in dead.stderr
 
 
 def test_kkt_generator_shapes_and_determinism():
