@@ -44,7 +44,8 @@ struct gbdpcg_context {
     };
     std::vector<PersistWs> pws;
     // cluster path (pcg_cluster.hip): hand-off slots, one per CU and epoch parity.  Made with the handle (its size does not
-    // depend on the shape) and zero-filled once: every launch leaves it zeroed again.
+    // depend on the shape) and zero-filled once; launches never clear it (a tag carries the launch number, and the word
+    // that counts launches lives in it).
     void *cluster_ws = nullptr;
     void *pws_last = nullptr;   // diagnostic builds only (gbdpcg_internal_persist_ws)
     // Buffers replaced by a larger one.  Graphs built earlier (gbdpcg_graph_create_solve_*, or a caller's own
@@ -233,6 +234,17 @@ gbdpcg_status get_pws(gbdpcg_handle_t h, uint32_t elem, uint32_t n, uint32_t N, 
     return GBDPCG_OK;
 }
 
+// Bytes of a shape's persistent-path buffer: the hand-off words, then (256-byte aligned) the vectors of its rescue launch
+// when the problem does not fit one workgroup's LDS.
+template <typename T> size_t persist_rescue_offset(uint32_t n, uint32_t N, uint32_t batch)
+{
+    return (persist_workspace_bytes<T>(n, N, batch) + 255) / 256 * 256;
+}
+template <typename T> size_t persist_total_bytes(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch)
+{
+    return persist_rescue_offset<T>(n, N, batch) + rescue_vec_bytes<T>(h->dev, n, N, batch);
+}
+
 gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
 {
     return grow_buffer(h, reinterpret_cast<void **>(&h->sym_flags), &h->sym_cap, batch);
@@ -254,9 +266,15 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
         void *pws = nullptr;
-        gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_workspace_bytes<T>(n, N, batch), !capturing, &pws);
+        gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_total_bytes<T>(h, n, N, batch), !capturing, &pws);
         if (st != GBDPCG_OK) return st;   // capturing a shape this handle has not seen: gbdpcg_reserve first
         HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
+        // The workgroups of that launch wait for each other inside the kernel; if they could not all get onto the device
+        // (somebody else's kernel holds compute units) they give up and leave the problem marked and untouched.  The
+        // reference refuses such a launch before it starts (checkPcgOccupancy, pcg.cuh:23-49); here a streaming launch
+        // queued behind it solves whatever carries the mark -- normally nothing: it then costs one empty launch.
+        a.rescue_vec = static_cast<unsigned char *>(pws) + persist_rescue_offset<T>(n, N, batch);
+        HIP_TRY(h, launch_pcg_rescue<T>(h->dev, a, stream));
     } else if (path == GBDPCG_PATH_FUSED) {
         // shapes the cluster kernel keeps resident in general storage gain nothing from symmetric STREAMING: only the
         // CU-resident symmetric kernel (N <= 128) is worth a symmetry test there
@@ -513,7 +531,7 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     DEVICE_SCOPE(h);
     if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT || pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT_1R) {
         void *pws = nullptr;
-        gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_workspace_bytes<T>(n, N, batch), true, &pws);
+        gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_total_bytes<T>(h, n, N, batch), true, &pws);
         if (st != GBDPCG_OK) return st;
     } else if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_SPLIT) {
         gbdpcg_status st = ensure_ws(h, split_workspace_bytes<T>(n, N, batch));
@@ -641,6 +659,7 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
     if (e == hipSuccess) e = hipMalloc(&h->cluster_ws, cluster_workspace_bytes(h->dev));
     if (e == hipSuccess) e = hipMemset(h->cluster_ws, 0, cluster_workspace_bytes(h->dev));
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the fill is done before any stream of the caller can use the handle
     if (e == hipSuccess) {
         h->d_exit = reinterpret_cast<uint8_t *>(h->d_iters) + 128;
         // coherent (fine-grained) mapping: the device-side bump of h_done must reach the host while the stream still runs
@@ -780,11 +799,11 @@ size_t gbdpcg_workspace_bytes(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n,
     if (elem_size == 8) {
         const gbdpcg_path p = pick_path<double>(h, n, N, batch);
         if (p == GBDPCG_PATH_FUSED) return 0;
-        return (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) ? persist_workspace_bytes<double>(n, N, batch) : split_workspace_bytes<double>(n, N, batch);
+        return (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) ? persist_total_bytes<double>(h, n, N, batch) : split_workspace_bytes<double>(n, N, batch);
     }
     const gbdpcg_path p = pick_path<float>(h, n, N, batch);
     if (p == GBDPCG_PATH_FUSED) return 0;
-    return (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) ? persist_workspace_bytes<float>(n, N, batch) : split_workspace_bytes<float>(n, N, batch);
+    return (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) ? persist_total_bytes<float>(h, n, N, batch) : split_workspace_bytes<float>(n, N, batch);
 }
 
 gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N, uint32_t batch)

@@ -33,8 +33,13 @@
 // check).  Otherwise, and always across XCDs, stores are sc1 (write-through).  Nothing depends on placement.
 // A cluster's workgroups must be resident together: the grid never exceeds one workgroup per CU, members of a cluster have
 // neighbouring block indices (in-order dispatch then splits at most one cluster at a time, and that one only until any
-// workgroup exits), and every spin is bounded: a cluster that cannot complete a hand-off reports max_iter_exit = 2,
-// iters = 0xffffffff for its problems.
+// workgroup exits), and every spin is bounded: a cluster that cannot complete a hand-off marks its problems
+// (iters = kItersGaveUp, max_iter_exit = 2, lambda / r / p untouched) and the RESCUE launch queued behind this kernel
+// (pcg_fused.hip, launch_pcg_rescue) solves them with the streaming kernel: no caller sees the mark.
+// A tag is {launch number mod 4095, + 1 : 12 bits | epoch : 20 bits} -- a fixed split, so launches with different
+// max_iter cannot produce each other's tags -- and every workgroup of a launch that owns a problem clears its own slot
+// (both parities) before HELLO, so a granule outlives at most the launches that own nothing: a stale one can only carry
+// the tag a launch polls for if its launch number is 4095 k launches old AND no launch in between owned a problem.
 #include <cstdlib>
 
 #include "bt_dense.hpp"
@@ -56,6 +61,7 @@ constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on 
 //   +256  the last own knot, for the right neighbour
 constexpr uint32_t kClCtrlBytes = 256, kClSlotBytes = 384, kClFirstOff = 128, kClLastOff = 256;
 constexpr uint32_t kClMaxH = 4;
+constexpr uint32_t kClEpochBits = 20, kClLaunchMod = 4095;   // tag = ((launch mod 4095) + 1) << 20 | epoch
 
 __device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
 
@@ -74,8 +80,12 @@ constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
 
 template <int NCT, int V, bool STAGED>
 __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsigned char *ws, uint32_t H, uint32_t C,
-                                                          uint32_t clusters, uint32_t spin_limit, uint32_t drop_block, bool no_plain, uint32_t epoch_bits)
+                                                          uint32_t clusters, uint32_t spin_limit, uint32_t drop_block, bool no_plain)
 {
+#ifndef GBDPCG_TEST_HOOKS
+    drop_block = 0xffffffffu;   // the hook that silences one workgroup exists in variants/libgbdpcg_hooks.so only
+#endif
+    constexpr uint32_t epoch_bits = kClEpochBits;
     using Dg = DenseGeom<float, NCT, V>;
     static_assert(NCT == 14 && V == 2 && Dg::WAVES == 8, "lane roles below are written for 7 lanes x 2 rows per knot");
     constexpr uint32_t n = NCT, THREADS = Dg::WAVES * 64, WINF = align16<float>((Dg::MAX_KNOTS + 2) * n);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #endif
 
     // this launch's number, in the tag bits above the epoch (epochs of a launch fit epoch_bits: the host checked)
-    const uint32_t nonce = (uint32_t)((__hip_atomic_load(reinterpret_cast<u64 *>(ws) + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull) << epoch_bits);
+    const uint32_t nonce = (uint32_t)(__hip_atomic_load(reinterpret_cast<u64 *>(ws) + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % kClLaunchMod + 1ull) << epoch_bits;
     bool greeted = false;     // HELLO done
     bool same_xcd = false;    // every member of the cluster runs on this XCD: publish with plain stores (set by HELLO)
     bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are reported, not solved
@@ -242,11 +252,27 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         const uint32_t left = (a.batch - first + clusters - 1) / clusters;
         any = pcg_takes_mask(a, first, clusters, left < 64 ? left : 64u, lane) != 0ull;
     }
+    if (any) {
+        // this workgroup's slot, both parities, cleared by the lanes that will publish into the same words (a wave's stores
+        // to one address arrive in order): tag 0 is nobody's
+        const cl_u32x2 z2 = {0u, 0u};
+        const cl_u32x4 z4 = {0u, 0u, 0u, 0u};
+        uint32_t lo = lane;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (uint32_t par = 0; par < 2; ++par) {
+            const uint32_t o = par * par_stride + my_slot;
+            if (lo == 0) __builtin_amdgcn_raw_buffer_store_b64(z2, region, (int)(o + wave * 8), 0, kClSc1);
+            if (wave == 0 && has_left && lo < n / 2) __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + kClFirstOff + lo * 16), 0, kClSc1);
+            if (wave == wl && has_right && lo - lb * (n / 2) < n / 2)
+                __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + kClLastOff + (lo - lb * (n / 2)) * 16), 0, kClSc1);
+        }
+    }
     if (any) for (uint32_t prob = c; prob < a.batch; prob += clusters) {
         if (!pcg_takes(a, prob)) continue;   // this launch is not the one that owns the problem (same verdict in every member)
         if (dead) {
             if (h == 0 && tid == 0) {
-                a.iters[prob] = 0xffffffffu;
+                a.iters[prob] = kItersGaveUp;
                 if (a.max_iter_exit) a.max_iter_exit[prob] = 2;
             }
             continue;
@@ -277,7 +303,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             if (bci[0] == 2u) {   // the cluster never got together: nothing of it is solved
                 dead = true;
                 if (h == 0 && tid == 0) {
-                    a.iters[prob] = 0xffffffffu;
+                    a.iters[prob] = kItersGaveUp;
                     if (a.max_iter_exit) a.max_iter_exit[prob] = 2;
                 }
                 wg_barrier();
@@ -490,7 +516,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
         }
         if (h == 0 && tid == 0) {
-            a.iters[prob] = failed ? 0xffffffffu : iter;
+            a.iters[prob] = failed ? kItersGaveUp : iter;
             if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (max_iter_exit ? 1 : 0);
         }
         dead = failed;
@@ -546,18 +572,15 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         const uint32_t rounds = (a.batch + clusters - 1) / clusters;
         // a tag = {launch number, epoch}: the epochs of a launch take the low epoch_bits of its 32 bits
         const double epochs = 2.0 + (double)rounds * (2.0 * a.max_iter + 4.0);
-        if (epochs >= (double)(1u << 20)) return false;
-        uint32_t epoch_bits = 1;
-        while ((double)(1u << epoch_bits) <= epochs) ++epoch_bits;
+        if (epochs >= (double)(1u << kClEpochBits)) return false;
         const uint32_t C = (a.N + H - 1) / H;
-        static const uint32_t spin_limit = [] {   // polls before a hand-off is given up (test hook; ~1 us per poll)
-            const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT");
-            return e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 21);
-        }();
-        static const uint32_t drop_block = [] {   // test hook: a workgroup that never publishes
-            const char *e = getenv("GBDPCG_CLUSTER_DROP_WG");
-            return e ? (uint32_t)strtoul(e, nullptr, 10) : 0xffffffffu;
-        }();
+        uint32_t spin_limit = 1u << 21;      // polls before a hand-off is given up (~1 us per poll: about two seconds)
+        uint32_t drop_block = 0xffffffffu;
+#ifdef GBDPCG_TEST_HOOKS
+        // variants/libgbdpcg_hooks.so only (tests/test_gpu_cluster.py): a short bound, and a workgroup that never publishes
+        if (const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT")) spin_limit = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv("GBDPCG_CLUSTER_DROP_WG")) drop_block = (uint32_t)strtoul(e, nullptr, 10);
+#endif
         // coalesced LDS-DMA tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
         static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
         const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
@@ -570,7 +593,7 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         }
         static const bool no_plain = getenv("GBDPCG_CLUSTER_NO_PLAIN") != nullptr;   // tuning runs: always sc1 stores
         hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, a, static_cast<unsigned char *>(a.cluster_ws), H, C,
-                           clusters, spin_limit, drop_block, no_plain, epoch_bits);
+                           clusters, spin_limit, drop_block, no_plain);
         *err = hipGetLastError();
         return true;
     } else {

@@ -85,11 +85,16 @@ __device__ __forceinline__ T wg_sum(T part, T *red, uint32_t lane, uint32_t wave
 
 // SYM: both matrices are symmetric block-tridiagonal (L_{k+1} == R_k^T) and are streamed through
 // SymStream (bt_sym.hpp): [D_k | R_k] only, 2/3 of the bytes.
-template <typename T, int NCT, int V, int WAVES, bool SYM>
+// GVEC (rescue launches of problems too large for one workgroup's LDS, see PcgArgs::rescue): the four vectors live in
+// device memory (a.rescue_vec, one carve per workgroup) instead of LDS -- written and read by this workgroup only, and
+// __syncthreads() orders a workgroup's global accesses on one CU -- and only the wave partials stay in LDS.  One workgroup
+// then pulls a problem of any size through one CU: slow (the fabric share of one CU), correct, and one launch.
+template <typename T, int NCT, int V, int WAVES, bool SYM, bool GVEC = false>
 __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
+    static_assert(!(GVEC && SYM), "rescue launches stream general storage");
 
     constexpr uint32_t THREADS = WAVES * 64;
     const uint32_t n = NCT ? (uint32_t)NCT : a.n;
@@ -98,8 +103,9 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps row bases in SGPRs
     const FusedCarve<T> cv(n, N, WAVES, SYM);
-    T *xa = smem + cv.xa, *xb = smem + cv.xb, *yc = smem + cv.yc, *lam = smem + cv.lam;
-    T *red0 = smem + cv.red, *red1 = red0 + WAVES;
+    T *vec = GVEC ? reinterpret_cast<T *>(a.rescue_vec) + (size_t)blockIdx.x * cv.red : smem;
+    T *xa = vec + cv.xa, *xb = vec + cv.xb, *yc = vec + cv.yc, *lam = vec + cv.lam;
+    T *red0 = GVEC ? smem : smem + cv.red, *red1 = red0 + WAVES;
     T *zc = smem + cv.zc;
     const LaneMap<NCT, V> m(n, lane);
     const StreamCtx<T, NCT, V> cx(m, lane);
@@ -108,8 +114,16 @@ __global__ __launch_bounds__(WAVES * 64) void pcg_fused_kernel(PcgArgs<T> a)
     SymStream<T, NCT, kPcgNT> ss;
     const size_t mstride = (size_t)3 * n * n * N;
 
-    for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x) {
-        if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
+    unsigned long long rescue_mask = 0ull;   // rescue launches: verdicts of this workgroup's next 64 problems, one round trip
+    uint32_t pi = 0;
+    for (uint32_t prob = blockIdx.x; prob < a.batch; prob += gridDim.x, ++pi) {
+        if (a.rescue) {
+            if ((pi & 63u) == 0u) {
+                const uint32_t left = (a.batch - prob + gridDim.x - 1) / gridDim.x;
+                rescue_mask = pcg_takes_mask(a, prob, gridDim.x, left < 64u ? left : 64u, lane);
+            }
+            if (!((rescue_mask >> (pi & 63u)) & 1ull)) continue;   // (normally every problem: nothing gave up)
+        } else if (!pcg_takes(a, prob)) continue;  // this launch is not the one that owns the problem
         const T *S = a.S + prob * mstride;
         const T *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;
         const T *gamma = a.gamma + (size_t)prob * len;
@@ -256,12 +270,16 @@ template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_
     return fused_lds_bytes<T>(n, N, 16) <= dev.lds_per_wg_max;
 }
 
-template <typename T, int NCT, int V, int WAVES, bool SYM = false>
+// Workgroups of a rescue launch: it normally owns nothing (one round trip per workgroup to find that out) and otherwise a
+// handful of problems, each of which one workgroup solves alone.
+constexpr uint32_t kRescueGrid = 64;
+
+template <typename T, int NCT, int V, int WAVES, bool SYM = false, bool GVEC = false>
 static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
 {
-    const size_t lds = (size_t)FusedCarve<T>(a.n, a.N, WAVES, SYM).total * sizeof(T);
-    if (lds > dev.lds_per_wg_max) return hipErrorInvalidValue;
-    auto kern = pcg_fused_kernel<T, NCT, V, WAVES, SYM>;
+    const size_t lds = GVEC ? (size_t)align16<T>(2 * WAVES) * sizeof(T) : (size_t)FusedCarve<T>(a.n, a.N, WAVES, SYM).total * sizeof(T);
+    if (lds > dev.lds_per_wg_max || (GVEC && !a.rescue_vec)) return hipErrorInvalidValue;
+    auto kern = pcg_fused_kernel<T, NCT, V, WAVES, SYM, GVEC>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -278,6 +296,7 @@ static hipError_t launch_fused_w(const DeviceInfo &dev, const PcgArgs<T> &a, hip
         return e ? atoi(e) : 0;
     }();
     if (grid_cap > 0 && grid > (uint32_t)grid_cap) grid = (uint32_t)grid_cap;
+    if (a.rescue && grid > kRescueGrid) grid = kRescueGrid;
     if (grid > a.batch) grid = a.batch;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
     return hipGetLastError();
@@ -296,7 +315,7 @@ static hipError_t launch_fused_v(const DeviceInfo &dev, const PcgArgs<T> &a, hip
         const char *e = getenv("GBDPCG_FUSED_WAVES");
         return e ? atoi(e) : 0;
     }();
-    int waves = a.batch < (uint32_t)dev.num_cus ? 16 : 8;
+    int waves = (a.batch < (uint32_t)dev.num_cus || a.rescue) ? 16 : 8;
     if (forced == 4 || forced == 8 || forced == 16) waves = forced;
     while (waves > 4 && fused_lds_bytes<T>(a.n, a.N, waves) > dev.lds_per_wg_max) waves /= 2;
     if constexpr (SymGeom<T, NCT>::OK) {
@@ -333,9 +352,14 @@ static hipError_t launch_fused_n(const DeviceInfo &dev, const PcgArgs<T> &a, int
 template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s)
 {
     hipError_t rerr = hipSuccess;
-    if (launch_pcg_resident<T>(dev, a, s, &rerr)) return rerr;  // small problems: pcg_resident.hip
-    if (a.symmetric && launch_pcg_resident_sym<T>(dev, a, s, &rerr)) return rerr;  // pcg_resident_sym.hip
-    if (!a.symmetric && launch_pcg_cluster<T>(dev, a, s, &rerr)) return rerr;      // general storage over 2-4 CUs: pcg_cluster.hip
+    if (!a.rescue) {   // (a rescue launch streams: the kernels below are what it backs)
+        if (launch_pcg_resident<T>(dev, a, s, &rerr)) return rerr;  // small problems: pcg_resident.hip
+        if (a.symmetric && launch_pcg_resident_sym<T>(dev, a, s, &rerr)) return rerr;  // pcg_resident_sym.hip
+        if (!a.symmetric && launch_pcg_cluster<T>(dev, a, s, &rerr)) {   // general storage over 2-4 CUs: pcg_cluster.hip
+            // the workgroups of a cluster wait for each other: whatever they could not solve together is solved here
+            return rerr == hipSuccess ? launch_pcg_rescue<T>(dev, a, s) : rerr;
+        }
+    }
     const void *ptrs[] = {a.S, a.Pinv};
     const int V = choose_vec<T>(a.n, ptrs, 2);
     if (V == 0) return hipErrorInvalidValue;
@@ -349,6 +373,34 @@ template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const P
     return launch_fused_n<T, 0>(dev, a, V, s);
 }
 
+template <typename T> size_t rescue_vec_bytes(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch)
+{
+    if (fused_fits<T>(dev, n, N)) return 0;
+    const uint32_t grid = batch < kRescueGrid ? batch : kRescueGrid;
+    return (size_t)grid * FusedCarve<T>(n, N, 16).red * sizeof(T);
+}
+
+template <typename T> hipError_t launch_pcg_rescue(const DeviceInfo &dev, PcgArgs<T> a, hipStream_t s)
+{
+#ifdef GBDPCG_TEST_HOOKS
+    // variants/libgbdpcg_hooks.so only: let a test see what the kernel that gave up left behind
+    if (getenv("GBDPCG_RESCUE_OFF")) return hipSuccess;
+#endif
+    a.rescue = true;
+    a.symmetric = false;      // general storage: the kernel reads L, D and R whatever the launch it backs assumed
+    a.host_done = nullptr;
+    if (fused_fits<T>(dev, a.n, a.N)) return launch_pcg_fused<T>(dev, a, s);
+    // vectors in device memory, runtime-n kernel (the block sizes that reach this are the persistent path's)
+    const void *ptrs[] = {a.S, a.Pinv};
+    const int V = choose_vec<T>(a.n, ptrs, 2);
+    if (V == 1) return launch_fused_w<T, 0, 1, 16, false, true>(dev, a, s);
+    if (V == 2) return launch_fused_w<T, 0, 2, 16, false, true>(dev, a, s);
+    if constexpr (sizeof(T) == 4) {
+        if (V == 4) return launch_fused_w<T, 0, 4, 16, false, true>(dev, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 template bool fused_has_symmetric<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
 template bool fused_has_symmetric<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
 template size_t fused_lds_bytes<float>(uint32_t, uint32_t, uint32_t);
@@ -357,5 +409,9 @@ template bool fused_fits<float>(const DeviceInfo &, uint32_t, uint32_t);
 template bool fused_fits<double>(const DeviceInfo &, uint32_t, uint32_t);
 template hipError_t launch_pcg_fused<float>(const DeviceInfo &, const PcgArgs<float> &, hipStream_t);
 template hipError_t launch_pcg_fused<double>(const DeviceInfo &, const PcgArgs<double> &, hipStream_t);
+template hipError_t launch_pcg_rescue<float>(const DeviceInfo &, PcgArgs<float>, hipStream_t);
+template hipError_t launch_pcg_rescue<double>(const DeviceInfo &, PcgArgs<double>, hipStream_t);
+template size_t rescue_vec_bytes<float>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
+template size_t rescue_vec_bytes<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t);
 
 }  // namespace gbdpcg

@@ -23,7 +23,12 @@
 //     from a per-problem base kept in the workspace, so nothing has to be cleared between launches and the whole
 //     solve is ONE kernel node in a hipGraph.
 //   * one workgroup per CU at most (grid <= CU count), every spin is bounded: a launch that cannot get all its
-//     workgroups resident gives up and reports max_iter_exit = 2 instead of hanging.
+//     workgroups resident gives up instead of hanging -- lambda, r, p untouched, d_iters = kItersGaveUp -- and the
+//     RESCUE launch queued behind it (api.hip, PcgArgs::rescue) solves the problem with a streaming kernel, so no
+//     caller sees the mark.  The epoch base of the next launch is stored by the workgroup that finishes LAST (an
+//     agent-scope counter tells it): a workgroup that only got onto the device after the others had given up still
+//     publishes under THIS launch's epochs, and whatever it leaves in its slots is older than anything the next launch
+//     polls for.
 #include <cstdlib>
 #include <type_traits>
 
@@ -34,13 +39,46 @@ namespace gbdpcg {
 
 typedef unsigned long long u64;
 
-constexpr uint32_t kPersistCtrl = 16;   // u64 control words per problem (a 128-byte line of their own)
+#define GBDPCG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// u64 control words per problem (lines of their own): [0] epoch base of the next launch, [1..15] stamps of the diagnostic
+// build, [16] workgroups of the running launch that have finished
+constexpr uint32_t kPersistCtrl = 32, kPersistFinished = 16;
+
+// The last workgroup of a problem's launch to get here stores the next launch's epoch base.  Every workgroup has read
+// `base` by then, and every granule this launch wrote carries a tag below base + span.
+__device__ __forceinline__ void persist_finish(u64 *ws, uint32_t W, uint32_t base, uint32_t span)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 before = __hip_atomic_fetch_add(ws + kPersistFinished, 1ull, GBDPCG_RLX_AGENT);
+    if (before == W - 1u) {
+        __hip_atomic_store(ws + kPersistFinished, 0ull, GBDPCG_RLX_AGENT);
+        __hip_atomic_store(ws, (u64)(base + span), GBDPCG_RLX_AGENT);
+    }
+}
+
+// tests/test_gpu_persist.py, variants/libgbdpcg_hooks.so only (-DGBDPCG_TEST_HOOKS): hold workgroup `hold_wg` of every
+// problem back for `hold_us` microseconds before it reads anything -- a workgroup that gets onto the device late.
+#ifdef GBDPCG_TEST_HOOKS
+#define GBDPCG_PERSIST_HOLD(BLOCK, HOLD_WG, HOLD_US)                                              \
+    if ((HOLD_US) != 0u && (BLOCK) == (HOLD_WG)) {                                                \
+        const u64 until = __builtin_amdgcn_s_memrealtime() + ((HOLD_US) == 0xffffffffu ? 0ull : (u64)(HOLD_US) * 100ull); \
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(64);            \
+    }
+// ... and GBDPCG_PERSIST_DROP_WG: the last workgroup of the grid leaves at once, publishing nothing (hold_us == 0xffffffff)
+#define GBDPCG_PERSIST_DROP(WS, W, BASE, SPAN, HOLD_US)                                           \
+    if ((HOLD_US) == 0xffffffffu && blockIdx.x == gridDim.x - 1u) {                               \
+        if (threadIdx.x == 0) persist_finish(WS, W, BASE, SPAN);                                  \
+        return;                                                                                   \
+    }
+#else
+#define GBDPCG_PERSIST_HOLD(BLOCK, HOLD_WG, HOLD_US)
+#define GBDPCG_PERSIST_DROP(WS, W, BASE, SPAN, HOLD_US)
+#endif
 
 template <typename T> struct Gran;
 template <> struct Gran<float> { static constexpr uint32_t PER = 1; };
 template <> struct Gran<double> { static constexpr uint32_t PER = 2; };
-
-#define GBDPCG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ void gran_store(u64 *slot, uint32_t epoch, float v)
 {
@@ -300,8 +338,12 @@ template <typename T, int NCT> struct PersistGeom {
 
 template <typename T, int NCT, int K, bool HAS_PINV>
 __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_kernel(PcgArgs<T> a, u64 *ws_all, uint32_t W,
-                                                                                     uint32_t spin_limit, uint32_t staged)
+                                                                                     uint32_t spin_limit, uint32_t staged,
+                                                                                     uint32_t hold_wg, uint32_t hold_us)
 {
+    GBDPCG_PERSIST_HOLD(blockIdx.x % W, hold_wg, hold_us)
+    (void)hold_wg;
+    (void)hold_us;
     using Gm = PersistGeom<T, NCT>;
     constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
     // PUB publishes the partial, HPUB the boundary knots (no global store by the polling wave 0 when there are others)
@@ -349,6 +391,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
         part, 0, (int)((persist_words<T>(n, N) - kPersistCtrl) * 8), 0x00020000);
     const uint32_t halo_base = (uint32_t)(persist_part_words<T>(N) * 8);
     const uint32_t base = (uint32_t)__hip_atomic_load(ws, GBDPCG_RLX_AGENT);   // epochs of this launch continue from here
+    GBDPCG_PERSIST_DROP(ws, W, base, 2u * a.max_iter + 8u, hold_us)
 
     // ---- resident matrices: this lane's COLS columns of its row, both matrices -----------------------------------
     T sreg[COLS], preg[COLS];
@@ -543,22 +586,21 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
 #undef GBDPCG_PERSIST_PHASE
 
     // ---- outputs (pcg.cuh:212,215) --------------------------------------------------------------------------------
-    const bool failed = bci[0] == 2u;
+    const bool failed = bci[0] == 2u;   // (the same verdict in every workgroup of the problem: all of them wait for all)
     const T beta = ran_out ? bc[2] : T(0);   // the last iteration did not break: it still ran p = r~ + beta p
     for (uint32_t i = tid; i < OWN; i += THREADS) {
         const uint32_t gi = k0 * n + i;
-        if (gi < len) {
+        if (gi < len && !failed) {   // a launch that gave up leaves lambda, r, p as it found them: the rescue launch starts there
             lambda[gi] = lam[i];
             if (a.r) a.r[(size_t)prob * len + gi] = rwin[rc][n + i];
             if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pwin[pc][n + i], twin[n + i]) : pwin[pc][n + i];
         }
     }
     if (w == 0 && tid == 0) {
-        a.iters[prob] = failed ? 0xffffffffu : (ran_out ? a.max_iter : bci[1]);
+        a.iters[prob] = failed ? kItersGaveUp : (ran_out ? a.max_iter : bci[1]);
         if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (ran_out ? 1 : 0);
-        // every workgroup read `base` before its first publish, and this workgroup has seen all of those
-        __hip_atomic_store(ws, (u64)(base + 2u * a.max_iter + 8u), GBDPCG_RLX_AGENT);
     }
+    if (tid == 0) persist_finish(ws, W, base, 2u * a.max_iter + 8u);
 }
 
 // ---- single-reduction variant (opt-in: GBDPCG_PATH_PERSISTENT_1R) ------------------------------------------------------
@@ -579,8 +621,12 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
 // tests/test_gpu_persist.py (a = 0.5 and a = 0.9 generators).  Two or three knots per workgroup only.
 template <typename T, int NCT, int K, bool HAS_PINV>
 __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_kernel(PcgArgs<T> a, u64 *ws_all, uint32_t W,
-                                                                                       uint32_t spin_limit)
+                                                                                       uint32_t spin_limit, uint32_t hold_wg,
+                                                                                       uint32_t hold_us)
 {
+    GBDPCG_PERSIST_HOLD(blockIdx.x % W, hold_wg, hold_us)
+    (void)hold_wg;
+    (void)hold_us;
     using Gm = PersistGeom<T, NCT>;
     static_assert(K >= 2, "the first and the last own knot carry one halo block-row each");
     constexpr uint32_t n = NCT, G = Gm::G, WPK = Gm::WPK, COLS = Gm::COLS, PER = Gran<T>::PER;
@@ -626,6 +672,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
         part, 0, (int)((persist_words<T>(n, N) - kPersistCtrl) * 8), 0x00020000);
     const uint32_t h_base = (uint32_t)(persist_part_words<T>(N) * 8);
     const uint32_t base = (uint32_t)__hip_atomic_load(ws, GBDPCG_RLX_AGENT);
+    GBDPCG_PERSIST_DROP(ws, W, base, 2u * a.max_iter + 8u, hold_us)
 
     // ---- resident block-rows: S and Pinv of the own knot, Pinv of the thread's halo knot ---------------------------
     T sreg[COLS], preg[COLS], hreg[COLS];
@@ -814,17 +861,17 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
     const T beta = ran_out ? bc[1] : T(0);   // max-iteration exit: the reference's last iteration still ran p = r~ + beta p
     for (uint32_t i = tid; i < OWN; i += THREADS) {
         const uint32_t gi = k0 * n + i;
-        if (gi < len) {
+        if (gi < len && !failed) {
             lambda[gi] = lam[i];
             if (a.r) a.r[(size_t)prob * len + gi] = rwin[2 * n + i];
             if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pown[i], uwin[2 * n + i]) : pown[i];
         }
     }
     if (w == 0 && tid == 0) {
-        a.iters[prob] = failed ? 0xffffffffu : bci[1];
+        a.iters[prob] = failed ? kItersGaveUp : bci[1];
         if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (ran_out ? 1 : 0);
-        __hip_atomic_store(ws, (u64)(base + 2u * a.max_iter + 8u), GBDPCG_RLX_AGENT);
     }
+    if (tid == 0) persist_finish(ws, W, base, 2u * a.max_iter + 8u);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -869,19 +916,23 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
 {
     const uint32_t W = (a.N + K - 1) / K;
     // ~1 us per failed pass: a launch whose workgroups are not all resident gives up after about two seconds.
-    // GBDPCG_PERSIST_SPIN_LIMIT / GBDPCG_PERSIST_DROP_WG exist for tests/test_gpu_persist.py only: a short bound, and
-    // a launch that is missing its last workgroup, to drive the give-up path.
-    static const uint32_t spin_limit = [] {
-        const char *e = getenv("GBDPCG_PERSIST_SPIN_LIMIT");
-        return e ? (uint32_t)atoi(e) : (1u << 21);
-    }();
-    static const uint32_t drop = getenv("GBDPCG_PERSIST_DROP_WG") ? 1u : 0u;
-    const dim3 grid(W * a.batch - (W * a.batch > 1 ? drop : 0u)), block(K * PersistGeom<T, NCT>::TPK);
+    uint32_t spin_limit = 1u << 21, hold_wg = 0u, hold_us = 0u;
+#ifdef GBDPCG_TEST_HOOKS
+    // variants/libgbdpcg_hooks.so only (tests/test_gpu_persist.py): a short spin bound, a launch that is missing its last
+    // workgroup, a workgroup that arrives late -- to drive the give-up path.  The shipped library has none of this.
+    if (const char *e = getenv("GBDPCG_PERSIST_SPIN_LIMIT")) spin_limit = (uint32_t)atoi(e);
+    if (const char *e = getenv("GBDPCG_PERSIST_HOLD_US")) {
+        hold_us = (uint32_t)atoi(e);
+        hold_wg = W - 1u;
+    }
+    if (getenv("GBDPCG_PERSIST_DROP_WG")) hold_us = 0xffffffffu;
+#endif
+    const dim3 grid(W * a.batch), block(K * PersistGeom<T, NCT>::TPK);
     u64 *ws = reinterpret_cast<u64 *>(workspace);
     if (one_reduction) {
         if constexpr (K >= 2) {
-            if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit);
-            else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit);
+            if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit, hold_wg, hold_us);
+            else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit, hold_wg, hold_us);
         } else {
             return hipErrorInvalidValue;
         }
@@ -898,7 +949,7 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, a, ws, W, spin_limit, staged ? 1u : 0u);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, ws, W, spin_limit, staged ? 1u : 0u, hold_wg, hold_us);
     }
     return hipGetLastError();
 }

@@ -1,6 +1,8 @@
 """The persistent single-launch path (csrc/pcg_persist.hip; BASELINE config 4: n = 36, N = 256, fp64, one problem)
 against the CPU oracle, through the C ABI.  Tolerances as in test_gpu_parity.py: fp64 1e-10, fp32 1e-6 norm-wise,
 equal iteration counts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -199,39 +201,81 @@ def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
 
 
 _GIVE_UP = r"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from gbd_pcg_amd import binding, synth
+from oracle import oracle as orc
 s = binding.Solver(0)
-s.set_path(binding.PATH_PERSISTENT if sys.argv[2] == "2r" else binding.PATH_PERSISTENT_1R)
-n, N = 36, 64
-d = synth.gen_numpy(n, N, seed=5, batch=1, dtype=np.float64)
-S, P, g = (torch.from_numpy(d[k]).cuda() for k in ("S", "Pinv", "gamma"))
-lam = torch.zeros_like(g)
-it, fl = s.solve(n, N, 1, S, P, g, lam, tol=1e-6, max_iter=30)
-torch.cuda.synchronize()
-print("RESULT", int(it.cpu().numpy().astype(np.uint32)[0]), int(fl[0]))
+form, n, N, dt = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), (np.float64 if sys.argv[5] == "f64" else np.float32)
+path = binding.PATH_PERSISTENT if form == "2r" else binding.PATH_PERSISTENT_1R
+s.set_path(path)
+assert s.choose_path(np.dtype(dt).itemsize, n, N, 1) == path
+rescued = "GBDPCG_RESCUE_OFF" not in os.environ
+tol = 1e-10 if dt == np.float64 else 1e-6
+for rnd, seed in enumerate((5, 6, 5)):   # changed inputs in the second round: nothing of the first may leak into it
+    d = synth.gen_numpy(n, N, seed=seed, batch=1, dtype=dt)
+    S, P, g = (torch.from_numpy(d[k]).cuda() for k in ("S", "Pinv", "gamma"))
+    lam = torch.full_like(g, 0.5)
+    r, p = torch.full_like(g, 7.0), torch.full_like(g, 7.0)
+    it, fl = s.solve(n, N, 1, S, P, g, lam, r, p, tol=1e-6, max_iter=30)
+    torch.cuda.synchronize()
+    it0, fl0 = int(it.cpu().numpy().astype(np.uint32)[0]), int(fl[0])
+    if not rescued:
+        assert it0 == 0xffffffff and fl0 == 2, (it0, fl0)
+        assert bool((lam == 0.5).all()) and bool((r == 7.0).all()) and bool((p == 7.0).all())   # untouched
+    else:
+        ob = orc.pcg_batch(n, N, 1, d["S"], d["Pinv"], d["gamma"], lambda0=np.full((1, n * N), 0.5, dt), tol=1e-6, max_iter=30)
+        err = np.linalg.norm(lam.cpu().numpy() - ob["lambda_"]) / np.linalg.norm(ob["lambda_"])
+        assert it0 == int(ob["iters"][0]) and fl0 == 0 and err < tol, (rnd, it0, ob["iters"], fl0, err)
+        assert np.abs(r.cpu().numpy() - ob["r"]).max() < 2e-5 * np.abs(d["gamma"]).max()
+    # the late workgroup is late ONCE: the launches that follow are healthy ones, on the persistent kernel itself
+    os.environ.pop("GBDPCG_PERSIST_HOLD_US", None)
+print("RESULT", "seen" if not rescued else "solved")
 """
+
+_HOOKS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gbd-pcg_amd", "csrc", "variants",
+                          "libgbdpcg_hooks.so")
+
+
+def _hooked(form, n, N, dt, **hooks):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(_HOOKS_LIB), "make -C gbd-pcg_amd/csrc builds variants/libgbdpcg_hooks.so"
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("GBDPCG_PERSIST_", "GBDPCG_RESCUE_"))}
+    env.update(GBDPCG_LIB=_HOOKS_LIB, PYTHONPATH=root, **hooks)
+    out = subprocess.run([sys.executable, "-c", _GIVE_UP, root, form, str(n), str(N), dt], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    return [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()[1]
 
 
 @pytest.mark.parametrize("form", ["2r", "1r"])
 def test_persistent_launch_gives_up_instead_of_hanging(form):
-    """A persistent launch whose workgroups are not all there (here: the last one is never launched,
-    GBDPCG_PERSIST_DROP_WG, with a short spin bound) must end by itself and say so: d_iters = 0xffffffff,
-    d_max_iter_exit = 2 (include/gbdpcg.h, GBDPCG_PATH_PERSISTENT).  The same process without the test hooks solves."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GBDPCG_PERSIST_DROP_WG="1", GBDPCG_PERSIST_SPIN_LIMIT="2000")
-    out = subprocess.run([sys.executable, "-c", _GIVE_UP, root, form], env=env, capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
-    assert int(line[1]) == 0xffffffff and int(line[2]) == 2, line
-    env = {k: v for k, v in os.environ.items() if not k.startswith("GBDPCG_PERSIST_")}
-    out = subprocess.run([sys.executable, "-c", _GIVE_UP, root, form], env=env, capture_output=True, text=True, timeout=120)
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
-    assert 5 <= int(line[1]) <= 15 and int(line[2]) == 0, line
+    """A persistent launch whose workgroups are not all there (fault injection of variants/libgbdpcg_hooks.so: the last
+    workgroup leaves at once, short spin bound; the shipped library has no such hook) must end by itself, mark the problem
+    (d_iters = 0xffffffff, d_max_iter_exit = 2) and leave lambda, r, p as it found them.  Seen with the rescue launch
+    switched off (GBDPCG_RESCUE_OFF, hooks build only)."""
+    assert _hooked(form, 36, 64, "f64", GBDPCG_PERSIST_DROP_WG="1", GBDPCG_PERSIST_SPIN_LIMIT="2000", GBDPCG_RESCUE_OFF="1") == "seen"
+
+
+@pytest.mark.parametrize("form,n,N,dt", [("2r", 36, 64, "f64"), ("1r", 36, 64, "f64"), ("2r", 14, 200, "f32"), ("2r", 36, 256, "f64")])
+def test_persistent_give_up_is_rescued(form, n, N, dt):
+    """The same fault with the library's default behaviour: the streaming launch queued behind the persistent one solves
+    the marked problem from the untouched inputs -- vectors in LDS where one workgroup holds them (n = 14, N = 200), in
+    device memory otherwise (n = 36: the GVEC form of pcg_fused.hip) -- and the caller gets the oracle's iteration count
+    and lambda, three solves in a row on changed inputs.  (What the reference guarantees by refusing a launch that
+    cannot be co-resident before it starts, /root/reference/include/pcg.cuh:23-49.)"""
+    assert _hooked(form, n, N, dt, GBDPCG_PERSIST_DROP_WG="1", GBDPCG_PERSIST_SPIN_LIMIT="2000") == "solved"
+
+
+@pytest.mark.parametrize("form", ["2r", "1r"])
+def test_late_workgroup_does_not_poison_the_next_launch(form):
+    """a workgroup that gets onto the device only after the others have given up (hook: it is held back for
+    20 ms, the others' spin bound is ~2 ms) still publishes under the epochs of ITS launch; the epoch base of the next
+    launch is stored by the workgroup that finishes last, so the next launch -- on changed inputs -- cannot take what the
+    late one left for its own hand-offs.  Every round must equal the oracle (the first through the rescue launch)."""
+    assert _hooked(form, 36, 64, "f64", GBDPCG_PERSIST_HOLD_US="20000", GBDPCG_PERSIST_SPIN_LIMIT="2000") == "solved"
 
 
 def test_alternating_shapes_on_one_handle(solver, orc):
