@@ -47,6 +47,7 @@ struct gbdpcg_context {
     // depend on the shape) and zero-filled once; launches never clear it (a tag carries the launch number, and the word
     // that counts launches lives in it).
     void *cluster_ws = nullptr;
+    void *cluster_rescue = nullptr;   // vectors of the cluster path's in-kernel rescue (cluster_rescue_bytes)
     void *pws_last = nullptr;   // diagnostic builds only (gbdpcg_internal_persist_ws)
     // Buffers replaced by a larger one.  Graphs built earlier (gbdpcg_graph_create_solve_*, or a caller's own
     // capture of gbdpcg_solve_*) hold the OLD pointers in their kernel nodes, so growth never frees: the old
@@ -234,15 +235,15 @@ gbdpcg_status get_pws(gbdpcg_handle_t h, uint32_t elem, uint32_t n, uint32_t N, 
     return GBDPCG_OK;
 }
 
-// Bytes of a shape's persistent-path buffer: the hand-off words, then (256-byte aligned) the vectors of its rescue launch
-// when the problem does not fit one workgroup's LDS.
+// Bytes of a shape's persistent-path buffer: the hand-off words, then (256-byte aligned) the vectors of the workgroup that
+// solves a problem alone when its launch could not get its workgroups together (pcg_stream.hpp).
 template <typename T> size_t persist_rescue_offset(uint32_t n, uint32_t N, uint32_t batch)
 {
     return (persist_workspace_bytes<T>(n, N, batch) + 255) / 256 * 256;
 }
-template <typename T> size_t persist_total_bytes(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch)
+template <typename T> size_t persist_total_bytes(gbdpcg_handle_t, uint32_t n, uint32_t N, uint32_t batch)
 {
-    return persist_rescue_offset<T>(n, N, batch) + rescue_vec_bytes<T>(h->dev, n, N, batch);
+    return persist_rescue_offset<T>(n, N, batch) + persist_rescue_bytes<T>(n, N, batch);
 }
 
 gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
@@ -260,6 +261,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     if (!mappable<T>(n)) return GBDPCG_ERR_UNSUPPORTED;
     PcgArgs<T> a{d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, tol, max_iter, n, N, batch, d_iters, d_exit};
     a.cluster_ws = h->cluster_ws;
+    a.rescue_vec = h->cluster_rescue;   // (the persistent path points it at its own buffer below)
     DEVICE_SCOPE(h);
     const gbdpcg_path path = pick_path<T>(h, n, N, batch);
     if (path == GBDPCG_PATH_PERSISTENT || path == GBDPCG_PATH_PERSISTENT_1R) {
@@ -268,13 +270,11 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
         void *pws = nullptr;
         gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_total_bytes<T>(h, n, N, batch), !capturing, &pws);
         if (st != GBDPCG_OK) return st;   // capturing a shape this handle has not seen: gbdpcg_reserve first
-        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
-        // The workgroups of that launch wait for each other inside the kernel; if they could not all get onto the device
-        // (somebody else's kernel holds compute units) they give up and leave the problem marked and untouched.  The
-        // reference refuses such a launch before it starts (checkPcgOccupancy, pcg.cuh:23-49); here a streaming launch
-        // queued behind it solves whatever carries the mark -- normally nothing: it then costs one empty launch.
+        // The workgroups of this launch wait for each other inside the kernel; if they cannot all get onto the device
+        // (somebody else's kernel holds compute units) they give up, and the one that leaves last solves the problem alone
+        // with these vectors (pcg_stream.hpp).  The reference refuses such a launch before it starts (pcg.cuh:23-49).
         a.rescue_vec = static_cast<unsigned char *>(pws) + persist_rescue_offset<T>(n, N, batch);
-        HIP_TRY(h, launch_pcg_rescue<T>(h->dev, a, stream));
+        HIP_TRY(h, launch_pcg_persist<T>(h->dev, a, pws, stream, path == GBDPCG_PATH_PERSISTENT_1R));
     } else if (path == GBDPCG_PATH_FUSED) {
         // shapes the cluster kernel keeps resident in general storage gain nothing from symmetric STREAMING: only the
         // CU-resident symmetric kernel (N <= 128) is worth a symmetry test there
@@ -659,6 +659,7 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_iters), 256);
     if (e == hipSuccess) e = hipMalloc(&h->cluster_ws, cluster_workspace_bytes(h->dev));
     if (e == hipSuccess) e = hipMemset(h->cluster_ws, 0, cluster_workspace_bytes(h->dev));
+    if (e == hipSuccess) e = hipMalloc(&h->cluster_rescue, cluster_rescue_bytes(h->dev));
     if (e == hipSuccess) e = hipDeviceSynchronize();   // the fill is done before any stream of the caller can use the handle
     if (e == hipSuccess) {
         h->d_exit = reinterpret_cast<uint8_t *>(h->d_iters) + 128;
@@ -668,6 +669,7 @@ gbdpcg_status gbdpcg_create(gbdpcg_handle_t *out, int device)
     if (e != hipSuccess) {
         if (h->d_iters) (void)hipFree(h->d_iters);
         if (h->cluster_ws) (void)hipFree(h->cluster_ws);
+        if (h->cluster_rescue) (void)hipFree(h->cluster_rescue);
         delete h;
         return GBDPCG_ERR_HIP;
     }
@@ -690,6 +692,7 @@ gbdpcg_status gbdpcg_destroy(gbdpcg_handle_t h)
     for (const auto &e : h->pws) (void)hipFree(e.buf);
     if (h->sym_flags) (void)hipFree(h->sym_flags);
     if (h->cluster_ws) (void)hipFree(h->cluster_ws);
+    if (h->cluster_rescue) (void)hipFree(h->cluster_rescue);
     for (void *old : h->retired) (void)hipFree(old);
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->h_iters) (void)hipHostFree(h->h_iters);

@@ -15,15 +15,15 @@ struct DeviceInfo {
     size_t lds_per_wg_max = 160 * 1024;
 };
 
-// What a kernel whose workgroups rendezvous in-kernel (pcg_cluster.hip, pcg_persist.hip) leaves in d_iters for a problem
-// whose workgroups could not meet: lambda, r, p untouched, d_max_iter_exit = 2.  The RESCUE launch that follows such a
-// kernel on the same stream (PcgArgs::rescue) owns exactly the problems that carry this mark.
+// What a kernel whose workgroups rendezvous in-kernel (pcg_cluster.hip, pcg_persist.hip) would leave in d_iters for a
+// problem whose workgroups could not meet (with d_max_iter_exit = 2; lambda, r, p untouched).  Callers never see it: the
+// workgroup of the problem that finishes last solves it alone inside the same launch (pcg_stream.hpp, stream_rescue);
+// only variants/libgbdpcg_hooks.so can switch that off (GBDPCG_RESCUE_OFF) to show the mark to a test.
 constexpr uint32_t kItersGaveUp = 0xffffffffu;
 
-// Does this launch own problem `prob`?  (see PcgArgs::sel, PcgArgs::rescue)
+// Does this launch own problem `prob`?  (see PcgArgs::sel)
 template <typename A> __device__ __forceinline__ bool pcg_takes(const A &a, uint32_t prob)
 {
-    if (a.rescue && a.iters[prob] != kItersGaveUp) return false;
     if (!a.sel) return true;
     bool sym = true;
     for (uint32_t c = 0; c < a.sel_stride; ++c) sym &= a.sel[(size_t)prob * a.sel_stride + c] == 1;
@@ -37,16 +37,13 @@ template <typename A> __device__ __forceinline__ bool pcg_takes(const A &a, uint
 template <typename A>
 __device__ __forceinline__ unsigned long long pcg_takes_mask(const A &a, uint32_t first, uint32_t step, uint32_t count, uint32_t lane)
 {
-    if (!a.sel && !a.rescue) return count >= 64 ? ~0ull : ((1ull << count) - 1ull);
+    if (!a.sel) return count >= 64 ? ~0ull : ((1ull << count) - 1ull);
     bool mine = false;
     if (lane < count) {
         const size_t prob = (size_t)first + (size_t)lane * step;
-        mine = !a.rescue || a.iters[prob] == kItersGaveUp;
-        if (a.sel) {
-            bool sym = true;
-            for (uint32_t c = 0; c < a.sel_stride; ++c) sym &= a.sel[prob * a.sel_stride + c] == 1;
-            mine = mine && sym == (a.want == 1);
-        }
+        bool sym = true;
+        for (uint32_t c = 0; c < a.sel_stride; ++c) sym &= a.sel[prob * a.sel_stride + c] == 1;
+        mine = sym == (a.want == 1);
     }
     return __ballot(mine);
 }
@@ -85,14 +82,11 @@ template <typename T> struct PcgArgs {
     // Cluster path (pcg_cluster.hip): the handle's hand-off slots (cluster_workspace_bytes; zero-filled once when the
     // handle is made, never cleared afterwards: a tag carries the launch number); nullptr: the path is not offered.
     void *cluster_ws = nullptr;
-    // RESCUE launch: a streaming launch queued behind a kernel whose workgroups rendezvous in-kernel; it owns the problems
-    // that kernel owned (same sel / want) AND gave up on (iters[prob] == kItersGaveUp) -- normally none -- and solves them
-    // from the untouched inputs, so that no caller ever sees the give-up mark (the reference refuses such a launch before
-    // it starts instead: checkPcgOccupancy, pcg.cuh:23-49).
-    bool rescue = false;
-    // Vectors of a rescue launch for problems too large for one workgroup's LDS (pcg_fused.hip, GVEC): per workgroup
-    // fused_gvec_elems() elements of device memory; nullptr: vectors in LDS.
+    // In-kernel rescue (pcg_stream.hpp): device memory for the vectors of the workgroup that solves a problem alone when
+    // the workgroups of its cluster / persistent launch could not meet -- rescue_vec_elems(n, N) elements per cluster
+    // (pcg_cluster.hip) or per problem (pcg_persist.hip).  rescue_off: hooks build only (the mark stays visible).
     void *rescue_vec = nullptr;
+    bool rescue_off = false;
 };
 
 // Widest per-lane vector (in elements) usable for this block size and these base pointers:
@@ -120,11 +114,6 @@ template <typename T> hipError_t launch_spmv(const DeviceInfo &dev, const SpmvAr
 template <typename T> size_t fused_lds_bytes(uint32_t n, uint32_t N, uint32_t waves);
 template <typename T> bool fused_fits(const DeviceInfo &dev, uint32_t n, uint32_t N);
 template <typename T> hipError_t launch_pcg_fused(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s);
-// The RESCUE launch behind a kernel that may give up (see PcgArgs::rescue): streaming kernels only, a small grid, vectors in
-// LDS when they fit one workgroup and in `a.rescue_vec` (rescue_vec_bytes, may be 0) otherwise.  `a` = the arguments of the
-// launch it backs.
-template <typename T> hipError_t launch_pcg_rescue(const DeviceInfo &dev, PcgArgs<T> a, hipStream_t s);
-template <typename T> size_t rescue_vec_bytes(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch);
 
 // ---- pcg_resident.hip : both matrices register-resident, one 8-wave workgroup per problem.
 // Returns false when the shape is not eligible (then nothing was launched).
@@ -141,6 +130,7 @@ bool launch_pcg_resident_sym(const DeviceInfo &dev, const PcgArgs<T> &a, hipStre
 // Workgroups per problem the cluster path would use; 0 = shape not handled (n = 14, fp32, 72 < N <= 288 only).
 template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N);
 size_t cluster_workspace_bytes(const DeviceInfo &dev);
+size_t cluster_rescue_bytes(const DeviceInfo &dev);   // PcgArgs::rescue_vec of a cluster launch
 // Returns false when the launch is not eligible (then nothing was launched).
 template <typename T>
 bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err);
@@ -157,6 +147,7 @@ hipError_t launch_pcg_split(const DeviceInfo &dev, const PcgArgs<T> &a, void *wo
 template <typename T>
 uint32_t persist_knots_per_wg(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, bool one_reduction = false);
 template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uint32_t batch);
+template <typename T> size_t persist_rescue_bytes(uint32_t n, uint32_t N, uint32_t batch);   // PcgArgs::rescue_vec of a persistent launch
 // workspace: persist_workspace_bytes, ZERO-FILLED once when allocated (epoch bases live there), never cleared again
 template <typename T>
 hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,

@@ -33,9 +33,10 @@
 // check).  Otherwise, and always across XCDs, stores are sc1 (write-through).  Nothing depends on placement.
 // A cluster's workgroups must be resident together: the grid never exceeds one workgroup per CU, members of a cluster have
 // neighbouring block indices (in-order dispatch then splits at most one cluster at a time, and that one only until any
-// workgroup exits), and every spin is bounded: a cluster that cannot complete a hand-off marks its problems
-// (iters = kItersGaveUp, max_iter_exit = 2, lambda / r / p untouched) and the RESCUE launch queued behind this kernel
-// (pcg_fused.hip, launch_pcg_rescue) solves them with the streaming kernel: no caller sees the mark.
+// workgroup exits), and every spin is bounded: a cluster that cannot complete a hand-off gives its remaining problems up
+// -- nothing of them is written -- and the member that LEAVES LAST (a per-cluster agent-scope counter tells it; the
+// others have left by then) solves them alone, streaming, inside this same launch (pcg_stream.hpp, stream_rescue): no
+// caller ever sees an unsolved problem, and a healthy launch pays one atomic per workgroup for it.
 // A tag is {launch number mod 4095, + 1 : 12 bits | epoch : 20 bits} -- a fixed split, so launches with different
 // max_iter cannot produce each other's tags -- and every workgroup of a launch that owns a problem clears its own slot
 // (both parities) before HELLO, so a granule outlives at most the launches that own nothing: a stale one can only carry
@@ -43,8 +44,7 @@
 #include <cstdlib>
 
 #include "bt_dense.hpp"
-#include "bt_device.hpp"
-#include "internal.hpp"
+#include "pcg_stream.hpp"
 
 namespace gbdpcg {
 
@@ -55,11 +55,13 @@ typedef unsigned int cl_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on gfx950: bit 4 = sc1
 
-// Workspace: [256-byte block: stamps of the diagnostic build, words 30 / 31 = finish counter / launch number | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
+// Workspace: [256-byte block: stamps of the diagnostic build, words 30 / 31 = finish counter / launch number |
+// per cluster two words: members that have left, and 2^32 - 1 - (first problem a member gave up on) maximised over the
+// members (0: none) | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
 //   +0    the 8 wave partials (8 granules)
 //   +128  the first own knot of the product vector, for the left neighbour  (n granules, two per 16-byte store)
 //   +256  the last own knot, for the right neighbour
-constexpr uint32_t kClCtrlBytes = 256, kClSlotBytes = 384, kClFirstOff = 128, kClLastOff = 256;
+constexpr uint32_t kClLeftOff = 256, kClCtrlBytes = 256 + 256 * 16, kClSlotBytes = 384, kClFirstOff = 128, kClLastOff = 256;
 constexpr uint32_t kClMaxH = 4;
 constexpr uint32_t kClEpochBits = 20, kClLaunchMod = 4095;   // tag = ((launch mod 4095) + 1) << 20 | epoch
 
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     __shared__ __attribute__((aligned(16))) float xa[WINF];   // window of p (lambda in the prologue): halo knot, own knots, halo knot
     __shared__ __attribute__((aligned(16))) float xb[WINF];   // window of r
     __shared__ float bc[4];       // [0] alpha / eta' of the phase just gathered, [1] beta
-    __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out
+    __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out; [2], [3] the rescue's bookkeeping
+    __shared__ float rescue_red[2 * Dg::WAVES];
     // the last GBDPCG_CL_PTAIL columns of this lane's block-row of Pinv (two rows each): see dense_mv, TAIL
     __shared__ __attribute__((aligned(16))) float2 ptail[(GBDPCG_CL_PTAIL ? GBDPCG_CL_PTAIL : 1) * THREADS];
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: dense_stage_lds_bytes (bt_dense.hpp)
@@ -231,7 +234,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     const uint32_t nonce = (uint32_t)(__hip_atomic_load(reinterpret_cast<u64 *>(ws) + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % kClLaunchMod + 1ull) << epoch_bits;
     bool greeted = false;     // HELLO done
     bool same_xcd = false;    // every member of the cluster runs on this XCD: publish with plain stores (set by HELLO)
-    bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are reported, not solved
+    bool dead = false;        // a hand-off of this cluster timed out: its remaining problems are left to the member that leaves last
+    uint32_t first_dead = 0xffffffffu;   // ... from this problem on
     // problems of this cluster SOLVED BY THIS LAUNCH so far: the epochs of a problem continue where the last one stopped.
     // Problems another launch owns do not count: the first epochs a launch polls for must be 1 and 2 whatever the batch
     // holds.
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     if (any) for (uint32_t prob = c; prob < a.batch; prob += clusters) {
         if (!pcg_takes(a, prob)) continue;   // this launch is not the one that owns the problem (same verdict in every member)
         if (dead) {
-            if (h == 0 && tid == 0) {
+            if (a.rescue_off && h == 0 && tid == 0) {   // (hooks build only: show the mark)
                 a.iters[prob] = kItersGaveUp;
                 if (a.max_iter_exit) a.max_iter_exit[prob] = 2;
             }
@@ -300,9 +304,10 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
             wg_barrier();
             same_xcd = bci[1] != 0u && !no_plain;
-            if (bci[0] == 2u) {   // the cluster never got together: nothing of it is solved
+            if (bci[0] == 2u) {   // the cluster never got together: nothing of it is solved here
                 dead = true;
-                if (h == 0 && tid == 0) {
+                first_dead = prob;
+                if (a.rescue_off && h == 0 && tid == 0) {
                     a.iters[prob] = kItersGaveUp;
                     if (a.max_iter_exit) a.max_iter_exit[prob] = 2;
                 }
@@ -515,17 +520,46 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 if (a.p) a.p[voff + grow0 + j] = pv[j];
             }
         }
-        if (h == 0 && tid == 0) {
+        if (h == 0 && tid == 0 && (!failed || a.rescue_off)) {
             a.iters[prob] = failed ? kItersGaveUp : iter;
             if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (max_iter_exit ? 1 : 0);
         }
         dead = failed;
+        if (failed) first_dead = prob;
         wg_barrier();   // the windows and bci are reused by the next problem
         GBDPCG_CL_STAMP_RT(20, 0, ordinal == 3)
         ++ordinal;
     }
 
     GBDPCG_CL_STAMP_RT(22, 0, true)
+    // ---- a cluster that could not meet: the member that leaves last solves what was given up, alone -------------------------
+    // Every member that gave up did so on the same problem (nobody gets past a problem without everybody's hand-offs; the
+    // one exception -- a member stalled for the whole spin bound exactly at a problem's last hand-off, which then finishes
+    // that problem while its partner has given it up -- is why the members report the problem and the smallest one wins:
+    // that problem is then solved again, by the streaming kernel, to the same tolerance).  The counter is bumped after the
+    // report (s_waitcnt in between), both with agent-scope atomics; the last member puts both words back.
+    if (any && !a.rescue_off && a.rescue_vec) {
+        u64 *left = reinterpret_cast<u64 *>(ws + kClLeftOff) + 2 * c;
+        if (tid == 0) {
+            if (dead) __hip_atomic_fetch_max(left + 1, (u64)(0xffffffffu - first_dead), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const u64 before = __hip_atomic_fetch_add(left, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t from = 0xffffffffu;
+            if (before == H - 1u) {
+                const u64 worst = __hip_atomic_exchange(left + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(left, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (worst != 0ull) from = 0xffffffffu - (uint32_t)worst;
+            }
+            bci[2] = from;
+        }
+        __syncthreads();
+        const uint32_t from = bci[2];
+        if (from != 0xffffffffu) {
+            float *vec = reinterpret_cast<float *>(a.rescue_vec) + (size_t)c * rescue_vec_elems<float>(n, N);
+            for (uint32_t prob = from; prob < a.batch; prob += clusters)
+                if (pcg_takes(a, prob)) stream_rescue<float, Dg::WAVES>(a, prob, vec, rescue_red);
+        }
+    }
     // ---- the workgroup that finishes last gives the next launch its number ------------------------------------------------
     // (every workgroup of this launch has read the number by then; the counter and the number are only ever touched with
     // agent-scope atomics)
@@ -559,6 +593,13 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
 // ... plus 16 bytes per CU behind the slots: start / end of every workgroup on the real-time clock (diagnostic build only)
 size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (size_t)2 * dev.num_cus * kClSlotBytes + (size_t)dev.num_cus * 16; }
 
+// Device memory for the in-kernel rescue: one set of vectors per cluster, sized for the longest horizon the path takes.
+size_t cluster_rescue_bytes(const DeviceInfo &dev)
+{
+    constexpr uint32_t per_wg = DenseGeom<float, 14, 2>::MAX_KNOTS;
+    return (size_t)(dev.num_cus / 2) * rescue_vec_elems<float>(14, kClMaxH * per_wg) * sizeof(float);
+}
+
 template <typename T>
 bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
 {
@@ -580,7 +621,12 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         // variants/libgbdpcg_hooks.so only (tests/test_gpu_cluster.py): a short bound, and a workgroup that never publishes
         if (const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT")) spin_limit = (uint32_t)strtoul(e, nullptr, 10);
         if (const char *e = getenv("GBDPCG_CLUSTER_DROP_WG")) drop_block = (uint32_t)strtoul(e, nullptr, 10);
+        const bool rescue_off = getenv("GBDPCG_RESCUE_OFF") != nullptr;   // show a test what a cluster that gave up leaves behind
+#else
+        const bool rescue_off = false;
 #endif
+        PcgArgs<T> ka = a;
+        ka.rescue_off = rescue_off;
         // coalesced LDS-DMA tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
         static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
         const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
@@ -592,7 +638,7 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
             if (*err != hipSuccess) return true;
         }
         static const bool no_plain = getenv("GBDPCG_CLUSTER_NO_PLAIN") != nullptr;   // tuning runs: always sc1 stores
-        hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, a, static_cast<unsigned char *>(a.cluster_ws), H, C,
+        hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, ka, static_cast<unsigned char *>(a.cluster_ws), H, C,
                            clusters, spin_limit, drop_block, no_plain);
         *err = hipGetLastError();
         return true;

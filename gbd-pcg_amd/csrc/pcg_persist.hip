@@ -23,17 +23,16 @@
 //     from a per-problem base kept in the workspace, so nothing has to be cleared between launches and the whole
 //     solve is ONE kernel node in a hipGraph.
 //   * one workgroup per CU at most (grid <= CU count), every spin is bounded: a launch that cannot get all its
-//     workgroups resident gives up instead of hanging -- lambda, r, p untouched, d_iters = kItersGaveUp -- and the
-//     RESCUE launch queued behind it (api.hip, PcgArgs::rescue) solves the problem with a streaming kernel, so no
-//     caller sees the mark.  The epoch base of the next launch is stored by the workgroup that finishes LAST (an
-//     agent-scope counter tells it): a workgroup that only got onto the device after the others had given up still
-//     publishes under THIS launch's epochs, and whatever it leaves in its slots is older than anything the next launch
-//     polls for.
+//     workgroups resident gives up instead of hanging -- nothing of the problem is written -- and the workgroup that
+//     finishes LAST (an agent-scope counter tells it; the others have left by then) solves the problem alone,
+//     streaming, inside this same launch (pcg_stream.hpp, stream_rescue): no caller sees an unsolved problem.  The
+//     same workgroup stores the epoch base of the next launch: a workgroup that only got onto the device after the
+//     others had given up still publishes under THIS launch's epochs, and whatever it leaves in its slots is older than
+//     anything the next launch polls for.
 #include <cstdlib>
 #include <type_traits>
 
-#include "bt_device.hpp"
-#include "internal.hpp"
+#include "pcg_stream.hpp"
 
 namespace gbdpcg {
 
@@ -45,16 +44,30 @@ typedef unsigned long long u64;
 // build, [16] workgroups of the running launch that have finished
 constexpr uint32_t kPersistCtrl = 32, kPersistFinished = 16;
 
-// The last workgroup of a problem's launch to get here stores the next launch's epoch base.  Every workgroup has read
-// `base` by then, and every granule this launch wrote carries a tag below base + span.
-__device__ __forceinline__ void persist_finish(u64 *ws, uint32_t W, uint32_t base, uint32_t span)
+// Leaving a problem's launch (all threads of the workgroup).  The last workgroup to get here stores the next launch's epoch
+// base -- every workgroup has read `base` by then, and every granule this launch wrote carries a tag below base + span --
+// and, if any workgroup reports that the launch gave up, solves the problem alone (the others have left and have written
+// nothing).  [kPersistFinished] counts the workgroups that have left, [kPersistFinished + 1] is non-zero once one of them
+// gave up; the last one puts both back.  red: 2 * WAVES elements of LDS, flag: one word of LDS.
+template <typename T, int WAVES>
+__device__ __forceinline__ void persist_leave(const PcgArgs<T> &a, uint32_t prob, u64 *ws, uint32_t W, uint32_t base, uint32_t span,
+                                              bool failed, T *red, uint32_t *flag)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const u64 before = __hip_atomic_fetch_add(ws + kPersistFinished, 1ull, GBDPCG_RLX_AGENT);
-    if (before == W - 1u) {
-        __hip_atomic_store(ws + kPersistFinished, 0ull, GBDPCG_RLX_AGENT);
-        __hip_atomic_store(ws, (u64)(base + span), GBDPCG_RLX_AGENT);
+    if (threadIdx.x == 0) {
+        if (failed) __hip_atomic_fetch_max(ws + kPersistFinished + 1, 1ull, GBDPCG_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u64 before = __hip_atomic_fetch_add(ws + kPersistFinished, 1ull, GBDPCG_RLX_AGENT);
+        uint32_t rescue = 0u;
+        if (before == W - 1u) {
+            rescue = __hip_atomic_exchange(ws + kPersistFinished + 1, 0ull, GBDPCG_RLX_AGENT) != 0ull ? 1u : 0u;
+            __hip_atomic_store(ws + kPersistFinished, 0ull, GBDPCG_RLX_AGENT);
+            __hip_atomic_store(ws, (u64)(base + span), GBDPCG_RLX_AGENT);
+        }
+        *flag = rescue;
     }
+    __syncthreads();
+    if (*flag != 0u && !a.rescue_off && a.rescue_vec)
+        stream_rescue<T, WAVES>(a, prob, reinterpret_cast<T *>(a.rescue_vec) + (size_t)prob * rescue_vec_elems<T>(a.n, a.N), red);
 }
 
 // tests/test_gpu_persist.py, variants/libgbdpcg_hooks.so only (-DGBDPCG_TEST_HOOKS): hold workgroup `hold_wg` of every
@@ -68,7 +81,7 @@ __device__ __forceinline__ void persist_finish(u64 *ws, uint32_t W, uint32_t bas
 // ... and GBDPCG_PERSIST_DROP_WG: the last workgroup of the grid leaves at once, publishing nothing (hold_us == 0xffffffff)
 #define GBDPCG_PERSIST_DROP(WS, W, BASE, SPAN, HOLD_US)                                           \
     if ((HOLD_US) == 0xffffffffu && blockIdx.x == gridDim.x - 1u) {                               \
-        if (threadIdx.x == 0) persist_finish(WS, W, BASE, SPAN);                                  \
+        persist_leave<T, NWAVES>(a, prob, WS, W, BASE, SPAN, true, rescue_red, bci + 3);          \
         return;                                                                                   \
     }
 #else
@@ -359,7 +372,8 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
     __shared__ __attribute__((aligned(16))) T lam[OWN];
     __shared__ T dots[NWAVES];   // per-wave shares of the inner product
     __shared__ T bc[4];          // [0] coefficient of the next phase, [1] eta, [2] beta of the last direction update
-    __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out), [1] iterations
+    __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out), [1] iterations, [3] persist_leave's flag
+    __shared__ T rescue_red[2 * NWAVES];
 
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -596,11 +610,11 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist_ke
             if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pwin[pc][n + i], twin[n + i]) : pwin[pc][n + i];
         }
     }
-    if (w == 0 && tid == 0) {
+    if (w == 0 && tid == 0 && (!failed || a.rescue_off)) {   // (rescue_off: hooks build only, to show the mark)
         a.iters[prob] = failed ? kItersGaveUp : (ran_out ? a.max_iter : bci[1]);
         if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (ran_out ? 1 : 0);
     }
-    if (tid == 0) persist_finish(ws, W, base, 2u * a.max_iter + 8u);
+    persist_leave<T, NWAVES>(a, prob, ws, W, base, 2u * a.max_iter + 8u, failed, rescue_red, bci + 3);
 }
 
 // ---- single-reduction variant (opt-in: GBDPCG_PATH_PERSISTENT_1R) ------------------------------------------------------
@@ -640,7 +654,8 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
     __shared__ __attribute__((aligned(16))) T lam[OWN], pown[OWN];
     __shared__ T dots_g[NWAVES], dots_d[NWAVES];
     __shared__ T bc[4];          // [0] alpha, [1] beta, [2] gamma_old, [3] alpha_old
-    __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out, 3 ran out), [1] iterations
+    __shared__ uint32_t bci[4];  // [0] stop (1 converged, 2 hand-off timed out, 3 ran out), [1] iterations, [3] persist_leave's flag
+    __shared__ T rescue_red[2 * NWAVES];
 
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -867,11 +882,11 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
             if (a.p) a.p[(size_t)prob * len + gi] = ran_out ? fma_t(beta, pown[i], uwin[2 * n + i]) : pown[i];
         }
     }
-    if (w == 0 && tid == 0) {
+    if (w == 0 && tid == 0 && (!failed || a.rescue_off)) {
         a.iters[prob] = failed ? kItersGaveUp : bci[1];
         if (a.max_iter_exit) a.max_iter_exit[prob] = failed ? 2 : (ran_out ? 1 : 0);
     }
-    if (tid == 0) persist_finish(ws, W, base, 2u * a.max_iter + 8u);
+    persist_leave<T, NWAVES>(a, prob, ws, W, base, 2u * a.max_iter + 8u, failed, rescue_red, bci + 3);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -911,6 +926,11 @@ template <typename T> size_t persist_workspace_bytes(uint32_t n, uint32_t N, uin
     return persist_words<T>(n, N) * sizeof(u64) * batch;
 }
 
+template <typename T> size_t persist_rescue_bytes(uint32_t n, uint32_t N, uint32_t batch)
+{
+    return rescue_vec_elems<T>(n, N) * sizeof(T) * batch;
+}
+
 template <typename T, int NCT, int K>
 static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction)
 {
@@ -926,13 +946,18 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
         hold_wg = W - 1u;
     }
     if (getenv("GBDPCG_PERSIST_DROP_WG")) hold_us = 0xffffffffu;
+    const bool rescue_off = getenv("GBDPCG_RESCUE_OFF") != nullptr;   // show a test what a launch that gave up leaves behind
+#else
+    const bool rescue_off = false;
 #endif
+    PcgArgs<T> ka = a;
+    ka.rescue_off = rescue_off;
     const dim3 grid(W * a.batch), block(K * PersistGeom<T, NCT>::TPK);
     u64 *ws = reinterpret_cast<u64 *>(workspace);
     if (one_reduction) {
         if constexpr (K >= 2) {
-            if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, a, ws, W, spin_limit, hold_wg, hold_us);
-            else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, a, ws, W, spin_limit, hold_wg, hold_us);
+            if (a.Pinv) hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, true>), grid, block, 0, s, ka, ws, W, spin_limit, hold_wg, hold_us);
+            else hipLaunchKernelGGL((pcg_persist1r_kernel<T, NCT, K, false>), grid, block, 0, s, ka, ws, W, spin_limit, hold_wg, hold_us);
         } else {
             return hipErrorInvalidValue;
         }
@@ -949,7 +974,7 @@ static hipError_t launch_persist_k(const PcgArgs<T> &a, void *workspace, hipStre
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, a, ws, W, spin_limit, staged ? 1u : 0u, hold_wg, hold_us);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, ka, ws, W, spin_limit, staged ? 1u : 0u, hold_wg, hold_us);
     }
     return hipGetLastError();
 }
@@ -974,6 +999,8 @@ template uint32_t persist_knots_per_wg<float>(const DeviceInfo &, uint32_t, uint
 template uint32_t persist_knots_per_wg<double>(const DeviceInfo &, uint32_t, uint32_t, uint32_t, bool);
 template size_t persist_workspace_bytes<float>(uint32_t, uint32_t, uint32_t);
 template size_t persist_workspace_bytes<double>(uint32_t, uint32_t, uint32_t);
+template size_t persist_rescue_bytes<float>(uint32_t, uint32_t, uint32_t);
+template size_t persist_rescue_bytes<double>(uint32_t, uint32_t, uint32_t);
 template hipError_t launch_pcg_persist<float>(const DeviceInfo &, const PcgArgs<float> &, void *, hipStream_t, bool);
 template hipError_t launch_pcg_persist<double>(const DeviceInfo &, const PcgArgs<double> &, void *, hipStream_t, bool);
 

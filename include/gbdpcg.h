@@ -57,11 +57,14 @@ typedef enum gbdpcg_path {
     GBDPCG_PATH_SPLIT = 2, /* many workgroups per problem, two launches per iteration, vectors in L2/HBM */
     GBDPCG_PATH_PERSISTENT = 3, /* one large problem over many CUs in ONE launch: block-rows register-resident for the
                                   whole solve (the reference's layout, pcg.cuh:104-110), two in-kernel all-gathers of
-                                  {partial inner product, boundary knots} per iteration instead of 4 grid.sync().  Needs
-                                  every workgroup resident at once (ceil(N/K) * batch <= CU count, K <= 4): do not run
-                                  other kernels on the device concurrently.  A launch that cannot get its workgroups
-                                  resident gives up after a bounded spin and reports d_max_iter_exit = 2,
-                                  d_iters = 0xffffffff (result invalid; use GBDPCG_PATH_SPLIT for such callers). */
+                                  {partial inner product, boundary knots} per iteration instead of 4 grid.sync().  Wants
+                                  every workgroup resident at once (ceil(N/K) * batch <= CU count, K <= 4).  The
+                                  reference refuses a launch that cannot be co-resident before it starts
+                                  (checkPcgOccupancy, pcg.cuh:23-49); here, if another kernel holds compute units for
+                                  about two seconds, the workgroups give up after a bounded spin WITHOUT having written
+                                  anything, and the one that leaves last solves the problem alone inside the same launch
+                                  (streaming kernel: slow, correct).  The caller always gets a solved problem; on a
+                                  device shared with long-running kernels GBDPCG_PATH_SPLIT avoids the wait. */
     GBDPCG_PATH_PERSISTENT_1R = 4 /* OPT-IN, never chosen by AUTO: the persistent launch with the single-reduction
                                   (Chronopoulos-Gear) recurrence -- u = Pinv r, w = S u, gamma = r.u and delta = u.w in ONE
                                   all-gather per iteration (the halo knots of u are recomputed, not exchanged),
@@ -105,12 +108,14 @@ gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n
  * boundary knots twice per iteration); 0 = the shape has no such form (stateSize 14, fp32, 72 < knotPoints <= 288 only)
  * and general storage is streamed every iteration. */
 uint32_t gbdpcg_cluster_members(uint32_t elem_size, uint32_t n, uint32_t N);
-/* The workgroups of one problem wait for each other inside the kernel (bounded spins), so they must get onto the device
+/* The workgroups of one problem wait for each other inside the kernel (bounded spins), so they should get onto the device
  * together: the launch never has more workgroups than compute units and keeps the members of a problem next to each other
  * in dispatch order, which is enough as long as other kernels on the device finish within about a second.  A problem whose
- * workgroups could not meet is reported with d_max_iter_exit = 2 and d_iters = 0xffffffff (lambda untouched); the other
- * problems of the batch are not affected.  Setting the environment variable GBDPCG_NO_CLUSTER before the first solve of a
- * process switches the form off (general storage is then streamed every iteration, 3.4x slower at the config-3 shape). */
+ * workgroups could not meet within the bound is not lost: nothing of it has been written, and the workgroup of its cluster
+ * that leaves last solves it (and the cluster's remaining problems) alone with the streaming kernel, inside the same
+ * launch; the other problems of the batch are not affected.  d_max_iter_exit is therefore always 0 or 1.  Setting the
+ * environment variable GBDPCG_NO_CLUSTER before the first solve of a process switches the form off (general storage is
+ * then streamed every iteration, 3.4x slower at the config-3 shape). */
 
 /* Symmetric storage.  S and Pinv of an MPC Schur system are symmetric block-tridiagonal, i.e. in
  * storage L_{k+1} == R_k^T for every knot (README.md:8; the symmetric-stair preconditioner of
