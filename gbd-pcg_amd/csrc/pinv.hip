@@ -20,6 +20,12 @@
 #include "bt_device.hpp"
 #include "internal.hpp"
 
+#ifndef GBDPCG_PINV_SKIP
+#define GBDPCG_PINV_SKIP 0     // timing builds of pinv_stair_mfma_kernel (WRONG results): 1 no elimination, 2 no products, 4 no stores
+#endif
+#ifndef GBDPCG_PINV_PACKED
+#define GBDPCG_PINV_PACKED 1   // 0: one row per instruction in the DPP elimination (A/B runs)
+#endif
 #ifndef GBDPCG_PINV_DPP
 #define GBDPCG_PINV_DPP 1   // 0: pivot columns of the one-launch stair kernel broadcast through LDS (A/B runs)
 #endif
@@ -301,8 +307,27 @@ template <int J, int M, typename T> __device__ __forceinline__ void stair_elimin
         const T piv = T(1) / cj[J];
         const bool is_j = l == (uint32_t)J;
         const T pr = is_j ? piv : col[J] * piv;
+#if GBDPCG_PINV_PACKED
+        if constexpr (sizeof(T) == 4 && M % 2 == 0) {
+            // two rows per instruction (schur.hip, quad_pivot): the pivot lane's "start from zero" is an exact packed multiply by
+            // 0 or 1 instead of a select per row, the update a packed fma -- the same fma on the same numbers, element for element
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const float keep = is_j ? 0.0f : 1.0f;
+            const f2 kk = {keep, keep}, npr = {-pr, -pr};
 #pragma unroll
-        for (int r = 0; r < M; ++r) col[r] = (r == J) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+            for (int r = 0; r + 1 < M; r += 2) {
+                const f2 c = {col[r], col[r + 1]}, b = {cj[r], cj[r + 1]};
+                const f2 v = __builtin_elementwise_fma(b, npr, c * kk);
+                col[r] = v.x;
+                col[r + 1] = v.y;
+            }
+            col[J] = pr;
+        } else
+#endif
+        {
+#pragma unroll
+            for (int r = 0; r < M; ++r) col[r] = (r == J) ? pr : fma_t(-cj[r], pr, is_j ? T(0) : col[r]);
+        }
         stair_eliminate<J + 1, M>(col, l);
     }
 }
@@ -760,6 +785,202 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
     }
 }
 
+// The one-launch stair for fp32, rebuilt around what the counters of the kernel above say (profiles/r03_pinv_ab.txt): it ran at
+// half the HBM rate with NOTHING saturated -- vector pipes 47-64 % busy, LDS 28 %, 14 GB/s per compute unit -- because every wave
+// walks a chain of dependent round trips (D blocks in, eliminate, then four pairs: R / L in, two products, results out) with a
+// kilobyte or two in flight.  Two changes:
+//   * ONE request per workgroup.  Everything a workgroup reads -- D_k0 .. D_k0+15 and the R_k / L_k+1 blocks between them -- is one
+//     contiguous run of 46 n^2 elements of S.  It is pulled into LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+//     instruction, no registers) before anything else happens: 36 KB in flight per workgroup, 108 KB per compute unit, and no
+//     memory read after it.  Pass 1 and the pair phase read their operands where the DMA put them.
+//   * The two n x n x n products of a pair on the MATRIX cores (v_mfma_f32_16x16x4_f32: exact fp32, an fma chain over k --
+//     cdna_hip_programming.md, "FP32-input MFMA"): 12 MFMAs per pair (32 cycles of the matrix pipe each, 8 of
+//     vector issue) instead of 2 x 56 fma + 56 LDS reads per lane.  The mirrored inverses lie in LDS as zero-padded 16 x 16
+//     images (16-float rows): the operand of lane (i, q = lane / 16), A[i][4q .. 4q+3], is ONE ds_read_b128 and k = 4q + kk is
+//     the k of MFMA step kk in both operands.  B (R_k, or L_{k+1}^T in the second pass of an asymmetric pair) is read straight
+//     from the raw run; its k = 14, 15 "pads" are whatever follows in the run (finite matrix data) and meet the zero pads of
+//     the inverse.  T1 = B^T Dk^-1 leaves W = Dk^-1 B in the registers as W[j][4q + i] on lane (j, q): exactly the A operand of
+//     X = W Dk1^-1 and the B operand of X^T = Dk1^-1 W^T, so both orientations of the result come out of four more MFMAs
+//     each without any lane movement: X^T (lane = row of X) is stored as R'_k, X (lane = column of X) as L'_{k+1} -- 56-byte
+//     runs per quarter and register, no transposition through LDS.  Both chains multiply the same pairs of numbers in the same
+//     k order (Dk1^-1 is mirrored exactly), so R'_k and L'_{k+1} are bit-for-bit transposes whenever S was: the property the
+//     symmetric solve kernels rely on.
+// Pass 1 (the inversions) is the DPP Gauss-Jordan of the kernel above; so are the verdict bytes and S_SYM.  S must be 16-byte
+// aligned (the launcher checks).  52 KB of LDS per workgroup: three workgroups per compute unit.
+typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NCT, bool S_SYM>
+__global__ __launch_bounds__(kPinvThreads) void pinv_stair_mfma_kernel(uint32_t N, uint32_t chunks, const float *__restrict__ S,
+                                                                      float *__restrict__ Pinv, uint8_t *__restrict__ verdicts)
+{
+    constexpr bool s_symmetric = S_SYM;
+    constexpr uint32_t n = NCT, nn = n * n, PAIRS = 15, LD = 16, IMG = LD * LD;
+    static_assert(n <= 16 && n % 2 == 0, "quarter-wave elimination, 16 x 16 MFMA images, 16-byte blocks");
+    constexpr uint32_t RAW = 46 * nn;                                  // D_k0 .. D_k0+15 with the R / L blocks between them
+    constexpr uint32_t PIECES = RAW / 4, ROUNDS = (PIECES + kPinvThreads - 1) / kPinvThreads;   // 16-byte pieces, per-thread rounds
+    __shared__ __attribute__((aligned(16))) float raw[ROUNDS * kPinvThreads * 4 + 8];   // (+8: the k = 14, 15 over-read of the last block)
+    __shared__ __attribute__((aligned(16))) float inv[16][IMG];        // mirrored D^-1 of knots k0 .. k0+15, (r, c) at r * 16 + c
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u, quarter = lane >> 4, l = lane & 15u;
+    const uint32_t prob = blockIdx.x / chunks, chunk = blockIdx.x - prob * chunks;
+    const uint32_t k0 = chunk * PAIRS;
+    const size_t pbase = (size_t)prob * 3 * nn * N;
+
+    {   // ---- the workgroup's whole input, one request: pieces past the end of the problem re-read its last piece (never used)
+        const size_t g0 = pbase + (size_t)k0 * 3 * nn + nn;            // D_k0
+        const size_t left = (size_t)3 * nn * N - ((size_t)k0 * 3 * nn + nn);   // elements from there to the end of the problem
+        const uint32_t have = left / 4 < PIECES ? (uint32_t)(left / 4) : PIECES;
+        const float *src = S + g0;
+#pragma unroll
+        for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+            const uint32_t piece = rd * kPinvThreads + wave * 64 + lane;
+            const uint32_t off = (piece < have ? piece : have - 1u) * 16u;
+            const uint32_t dst = (uint32_t)(uintptr_t)raw + (rd * kPinvThreads + wave * 64) * 16u;   // wave-uniform; the lane's 16 bytes follow
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(src), "v"(off), "s"(dst) : "memory");
+        }
+        if (threadIdx.x < 8) raw[ROUNDS * kPinvThreads * 4 + threadIdx.x] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    {   // ---- pass 1: invert D_{k0 + slot}, slot = 4 wave + quarter
+        const uint32_t slot = wave * 4 + quarter, k = k0 + slot;
+        const bool alive = k < N, owner = l < n;
+        const float *D = raw + slot * 3 * nn;
+        float col[n];
+#pragma unroll
+        for (uint32_t r = 0; r < n; ++r) col[r] = (!alive || !owner) ? (r == l ? 1.f : 0.f) : D[l * n + r];
+#if !(GBDPCG_PINV_SKIP & 1)
+        stair_eliminate<0, (int)n>(col, l);
+#endif
+        if (owner) {  // mirrored on the way into LDS: element (r, c) with r > c takes the value of (c, r)
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r)
+                if (r <= l) inv[slot][l * LD + r] = col[r];       // upper triangle of column l, as computed
+#pragma unroll
+            for (uint32_t r = 0; r < n; ++r)
+                if (r < l) inv[slot][r * LD + l] = col[r];        // its mirror image: (l, r) := (r, l)
+        }
+        // zero pads: rows / columns n .. 15 of the image (what they meet in the other operand is finite, so the sum is exact)
+        if constexpr (n < LD) {
+            if (l >= n) {
+#pragma unroll
+                for (uint32_t r = 0; r < LD; ++r) inv[slot][l * LD + r] = 0.f;
+            } else {
+#pragma unroll
+                for (uint32_t c = n; c < LD; ++c) inv[slot][l * LD + c] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- D slots of the knot that ends the problem and the two corner blocks nobody reads (see the kernel above)
+    const uint32_t own_end = (chunk == chunks - 1) ? N : min(N, k0 + PAIRS);
+    if (own_end == N) {
+        float *o = Pinv + pbase + (size_t)(N - 1) * 3 * nn;
+        for (uint32_t i = threadIdx.x; i < nn; i += kPinvThreads) {
+            const uint32_t c = i / n, r = i - c * n;
+            o[nn + i] = inv[N - 1 - k0][c * LD + r];
+            o[2 * nn + i] = 0.f;
+        }
+    }
+    if (k0 == 0)
+        for (uint32_t i = threadIdx.x; i < nn; i += kPinvThreads) Pinv[pbase + i] = 0.f;
+
+    // ---- pass 2: pairs (k, k+1), k = k0 + j, j = wave, wave + 4, ...: nothing but LDS reads, MFMAs and stores
+    constexpr uint32_t EPL = (nn + 63) / 64;
+    const uint32_t lc = l < n ? l : n - 1;   // lanes 14, 15 of a quarter compute rows / columns nobody stores: any finite operand
+    bool any_asymmetric = false;
+    for (uint32_t j = wave; j < PAIRS && k0 + j + 1 < N; j += 4) {
+        const uint32_t k = k0 + j;
+        const float *A = inv[j], *C = inv[j + 1];
+        const float *Rk = raw + j * 3 * nn + nn, *Lk1 = Rk + nn;          // R_k(r,c) at c n + r, L_{k+1}(r,c) likewise
+        const size_t blk = pbase + (size_t)k * 3 * nn, nb = blk + (size_t)3 * nn;
+        bool differs = false;
+        if (!s_symmetric) {
+#pragma unroll
+            for (uint32_t q = 0; q < EPL; ++q) {
+                const uint32_t i = lane + 64 * q;
+                if (i < nn) {
+                    const uint32_t c = i / n, r = i - c * n;
+                    differs |= pinv_bits(Rk[i]) != pinv_bits(Lk1[r * n + c]);   // R_k(r,c) against L_{k+1}(c,r)
+                }
+            }
+        }
+        const bool symmetric = s_symmetric || __builtin_amdgcn_ballot_w64(differs) == 0;  // wave-uniform
+        any_asymmetric |= !symmetric;
+        // the D'_k block goes out in front of R'_k (one contiguous run of the row)
+        {
+            float *Dp = Pinv + blk + (size_t)nn;
+#pragma unroll
+            for (uint32_t q = 0; q < EPL; ++q) {
+                const uint32_t i = lane + 64 * q;
+                if (i < nn) {
+                    const uint32_t c = i / n, r = i - c * n;
+#if GBDPCG_PINV_SKIP & 4
+                    if (A[c * LD + r] == 1.2345f)
+#endif
+                    Dp[i] = A[c * LD + r];
+                }
+            }
+        }
+        const mf_f32x4 a4 = *reinterpret_cast<const mf_f32x4 *>(A + l * LD + 4 * quarter);   // Dk^-1 (4q + kk, l), symmetric
+        const mf_f32x4 c4 = *reinterpret_cast<const mf_f32x4 *>(C + l * LD + 4 * quarter);   // Dk1^-1 (l, 4q + kk) = (4q + kk, l)
+        for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
+            mf_f32x4 b4;   // B(4q + kk, l): B = R_k, then (asymmetric pair) L_{k+1}^T
+            if (pass == 0) {
+                const mf_f32x2 lo = *reinterpret_cast<const mf_f32x2 *>(Rk + lc * n + 4 * quarter);
+                const mf_f32x2 hi = *reinterpret_cast<const mf_f32x2 *>(Rk + lc * n + 4 * quarter + 2);
+                b4 = mf_f32x4{lo.x, lo.y, hi.x, hi.y};
+            } else {
+                const float *col0 = Lk1 + (4 * quarter) * n + lc;     // L_{k+1}(l, 4q + kk) at (4q + kk) n + l
+                b4 = mf_f32x4{col0[0], col0[n], col0[2 * n], col0[3 * n]};
+            }
+            mf_f32x4 t = {0.f, 0.f, 0.f, 0.f}, x = t, xt = t;
+#if GBDPCG_PINV_SKIP & 2
+            x = b4 + a4; xt = b4 + c4;
+#else
+            // T1 = B^T Dk^-1: t[i] on lane (j, q) = W[j][4q + i], W = Dk^-1 B
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(b4.x, a4.x, t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(b4.y, a4.y, t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(b4.z, a4.z, t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(b4.w, a4.w, t, 0, 0, 0);
+            // X = W Dk1^-1 (lane = column of X) and X^T = Dk1^-1 W^T (lane = row of X): the same products in the same order
+            x = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, c4.x, x, 0, 0, 0);
+            xt = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.x, t.x, xt, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, c4.y, x, 0, 0, 0);
+            xt = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.y, t.y, xt, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, c4.z, x, 0, 0, 0);
+            xt = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.z, t.z, xt, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, c4.w, x, 0, 0, 0);
+            xt = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.w, t.w, xt, 0, 0, 0);
+#endif
+            // R'_k(r, c) = -X(r, c) at c n + r: lane (j, q'), register i holds X^T[4q' + i][j] = X(j, 4q' + i)
+            // L'_{k+1}(r, c) = -X(c, r) at c n + r: lane (j, q'), register i holds X[4q' + i][j]
+            float *Rp = Pinv + blk + 2 * (size_t)nn, *Lp = Pinv + nb;
+            const float xr[4] = {xt.x, xt.y, xt.z, xt.w}, xl[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t c = 4 * quarter + i;
+#if GBDPCG_PINV_SKIP & 4
+                if (l < n && c < n && xr[i] == 1.2345f && xl[i] == 5.4321f) {   // timing build: no result store
+#else
+                if (l < n && c < n) {
+#endif
+                    if (pass == 0) Rp[c * n + l] = -xr[i];
+                    if (pass == 1 || symmetric) Lp[c * n + l] = -xl[i];
+                }
+            }
+        }
+    }
+    if (verdicts) {  // uniform branch: every wave reaches the barrier
+        const int bad = __syncthreads_or(any_asymmetric ? 1 : 0);
+        if (threadIdx.x == 0) verdicts[(size_t)prob * chunks + chunk] = bad ? 0 : 1;
+    }
+}
+
 // Stair slots for 32 < n <= 64 (even n; BASELINE config 4): one WORKGROUP per knot pair (k, k+1).  The same
 // operation sequence as the wave-per-pair kernels above -- W = D_k^-1 R_k with 2 x 2 register tiles, X = W D_{k+1}^-1,
 // R'_k = -X, and L'_{k+1} = -X^T written as the mirror image when the workgroup finds L_{k+1} == R_k^T in S (else a
@@ -917,6 +1138,19 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
                 const uint32_t chunks = pinv_verdict_chunks<T>(n, N, kind);                                          \
                 if (chunks) {                                                                                        \
                     if ((uint64_t)chunks * batch > 0x7fffffffull) return hipErrorInvalidValue;                       \
+                    if constexpr (sizeof(T) == 4 && NN >= 14) {   /* measured: -6 % at 14, -32 % at 16, slower at 8 and 12 */  \
+                        static const bool no_mfma = getenv("GBDPCG_PINV_NO_MFMA") != nullptr; /* tuning runs only */ \
+                        if (!no_mfma && reinterpret_cast<uintptr_t>(S) % 16 == 0) {   /* (LDS-DMA in 16-byte pieces) */ \
+                            const dim3 grid(chunks * batch);                                                         \
+                            if (s_symmetric)                                                                         \
+                                hipLaunchKernelGGL((pinv_stair_mfma_kernel<NN, true>), grid, dim3(kPinvThreads), 0, s, N, chunks, \
+                                                   (const float *)S, (float *)Pinv, verdicts);                       \
+                            else                                                                                     \
+                                hipLaunchKernelGGL((pinv_stair_mfma_kernel<NN, false>), grid, dim3(kPinvThreads), 0, s, N, chunks, \
+                                                   (const float *)S, (float *)Pinv, verdicts);                       \
+                            return hipGetLastError();                                                                \
+                        }                                                                                            \
+                    }                                                                                                \
                     if (s_symmetric)                                                                                     \
                         hipLaunchKernelGGL((pinv_stair_fused_kernel<T, NN, true>), dim3(chunks * batch), dim3(kPinvThreads), 0,  \
                                            s, N, chunks, S, Pinv, verdicts);                                             \

@@ -287,6 +287,15 @@ def test_register_resident_kernel_of_the_small_blocks(solver, orc, dtype, n):
     for k in ("lambda_", "r", "p"):
         for b in range(B):
             assert relerr(out[k][b], ob[k][b]) < 20 * tol, (k, b)
+    # ... and the same without a preconditioner: the loose band above (exit iteration within 3, lambda to the
+    # conditioning of S) would let a halo or summation bug of the Pinv = NULL branch through; four fixed iterations do not
+    # depend on where the exit test fires, so lambda, r and p are held to the same 20 * tol as with Pinv
+    ob = orc.pcg_batch(n, N, B, d["S"], None, d["gamma"], tol=0.0, max_iter=4, lambda0=lam0)
+    out = gpu_solve(solver, n, N, B, d["S"], None, d["gamma"], lam0=lam0, tol=0.0, max_iter=4)
+    assert (out["iters"] == 4).all() and out["max_iter_exit"].all()
+    for k in ("lambda_", "r", "p"):
+        for b in range(B):
+            assert relerr(out[k][b], ob[k][b]) < 20 * tol, (k, b)
     assert solver.choose_path(np.dtype(dtype).itemsize, n, top, 1) == binding.PATH_FUSED
     # the first launch of a shape may be the capture of a graph (the workgroups-per-CU query happens inside it)
     N, B = max(2, top // 3), 7
