@@ -1036,8 +1036,8 @@ gbdpcg_status gbdpcg_csr_to_bt_f64(uint32_t n, uint32_t N, const uint32_t *row_p
 
 const char *gbdpcg_version(void) { return "gbdpcg 0.1 gfx950"; }
 
-#ifdef GBDPCG_CL_STAMPS
-// diagnostic build only (tools/cluster_stamps.py): the cluster path's control block holds the stamps
+#if defined(GBDPCG_CL_STAMPS) || defined(GBDPCG_RS_STAMPS)
+// diagnostic builds only (tools/cluster_stamps.py, tools/rs_stamps.py): the cluster path's workspace holds the stamps
 void *gbdpcg_internal_cluster_ws(gbdpcg_handle_t h) { return h ? h->cluster_ws : nullptr; }
 #endif
 

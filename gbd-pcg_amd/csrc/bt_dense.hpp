@@ -149,51 +149,119 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
     }
 }
 
-// Staged tile loads.  A wave's knots are contiguous in memory; one block (L, D or R: n^2 floats = 49 pieces of 16 bytes)
-// of each of its up to 9 knots is fetched per stage with 7 LDS-DMA instructions (64 lanes x 16 bytes, dense and
-// coalesced, no VGPR in between) into the wave's own staging buffer, and the lanes then pick their two rows up with
-// 8-byte LDS reads.  The direct form (bt_dense.hpp, dense_load) reads 8 bytes per lane at a 56-byte stride: 84 sparse
-// instructions per matrix, bound by the address path -- in pcg_cluster.hip 28 us of a 40 us round went there.
-constexpr uint32_t kDenseStageChunks = 7 * 64, kDenseStageBytes = kDenseStageChunks * 16, kDenseStageFloats = kDenseStageBytes / 4;
-constexpr uint32_t kDensePieces = 49;   // 16-byte pieces per n x n block, n = 14
+// Staged tile loads (fp32, V = 2, even n with n^2 % 4 == 0).  A wave's knots are contiguous in memory; one block (L, D or R:
+// n^2 floats = n^2 / 4 pieces of 16 bytes) of each of its up to BPW knots is fetched per stage with LOADS LDS-DMA instructions
+// (64 lanes x 16 bytes, dense and coalesced, no VGPR in between; n = 14: 9 knots x 49 pieces, 7 instructions) into the wave's
+// own staging buffer, and the lanes then pick their two rows up with 8-byte LDS reads.  The direct form (dense_load above)
+// reads 8 bytes per lane at an n-float stride: 6 n sparse instructions per matrix, bound by the address path -- in
+// pcg_cluster.hip 28 us of a 40 us round went there.
+template <int NCT, int V> struct DenseStage {
+    using Dg = DenseGeom<float, NCT, V>;
+    static constexpr uint32_t PIECES = NCT * NCT / 4;                            // 16-byte pieces per n x n block
+    static constexpr uint32_t LOADS = (Dg::BPW * PIECES + 63) / 64;              // LDS-DMA instructions per stage
+    static constexpr uint32_t BYTES = LOADS * 64 * 16, FLOATS = BYTES / 4;       // one staging buffer of one wave
+    static_assert(V == 2 && NCT % 2 == 0 && (NCT * NCT) % 4 == 0, "whole 16-byte pieces per block, two rows per lane");
+    static_assert(LOADS >= 1 && LOADS <= 8, "a stage is counted on vmcnt");
+};
 
-// Issue one stage: lane l of instruction i moves the 16-byte piece q = 64 i + l of the wave's `nk` blocks (49 pieces each, blocks
+// Issue one stage: lane l of instruction i moves the 16-byte piece q = 64 i + l of the wave's `nk` blocks (PIECES each, blocks
 // 3 n^2 floats apart) from base to lds_addr + 16 q.  Lanes beyond the last piece re-read piece 0 into slots nobody picks
-// up: every lane of every instruction is live, so a stage is always exactly 7 loads on the wave's counter.  The offsets
+// up: every lane of every instruction is live, so a stage is always exactly LOADS loads on the wave's counter.  The offsets
 // are recomputed from the lane number at every issue (kept in registers across the stages they were spilled, and every
 // reload from scratch came with an s_waitcnt vmcnt(0) that drained the stages in flight).  The loads are written in asm
 // (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with dense_stage_wait before
 // it reads the buffer, and never has more than two stages in flight.
+template <int NCT, int V>
 __device__ __forceinline__ void dense_stage_issue(const float *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
 {
+    using St = DenseStage<NCT, V>;
     uint32_t lo = lane;
     asm volatile("" : "+v"(lo));
-    uint32_t rel[7];
+    uint32_t rel[St::LOADS];
 #pragma unroll
-    for (uint32_t i = 0; i < 7; ++i) {
-        const uint32_t q = i * 64 + lo, j = (q * 1338u) >> 16;   // q / 49 for q < 448
-        rel[i] = j < nk ? q * 16 + j * (3 * 14 * 14 * 4 - kDensePieces * 16) : 0u;
+    for (uint32_t i = 0; i < St::LOADS; ++i) {
+        const uint32_t q = i * 64 + lo, j = q / St::PIECES;   // (a constant divisor: multiply and shift)
+        rel[i] = j < nk ? q * 16 + j * (3 * NCT * NCT * 4 - St::PIECES * 16) : 0u;
     }
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
-                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "s"(lds_addr)
-                 : "memory", "scc");
+    // ONE asm statement per stage: M0 must not be touched by anything the compiler schedules in between
+    if constexpr (St::LOADS == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "s"(lds_addr)
+                     : "memory", "scc");
+    }
+    else if constexpr (St::LOADS == 5) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "s"(lds_addr)
+                     : "memory", "scc");
+    }
+    else if constexpr (St::LOADS == 6) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "s"(lds_addr)
+                     : "memory", "scc");
+    }
+    else if constexpr (St::LOADS == 7) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "s"(lds_addr)
+                     : "memory", "scc");
+    }
+    else if constexpr (St::LOADS == 8) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                     "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "v"(rel[7]), "s"(lds_addr)
+                     : "memory", "scc");
+    }
+    else static_assert(St::LOADS >= 4 && St::LOADS <= 8, "stage sizes written out: 4 .. 8 loads");
 }
-// all but the youngest `newer` stages (7 loads each) of this wave have landed
-template <int NEWER> __device__ __forceinline__ void dense_stage_wait()
+// all but the youngest `newer` stages (LOADS loads each) of this wave have landed
+template <int NCT, int V, int NEWER> __device__ __forceinline__ void dense_stage_wait()
 {
     if constexpr (NEWER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DenseStage<NCT, V>::LOADS) : "memory");
 }
 
 typedef float2 __attribute__((may_alias)) dense_float2_alias;
@@ -216,7 +284,7 @@ __device__ __forceinline__ void dense_stage_pick(const float *buf, const DenseCt
 }
 
 
-template <int NCT, int V> constexpr size_t dense_stage_lds_bytes() { return (size_t)2 * DenseGeom<float, NCT, V>::WAVES * kDenseStageBytes; }
+template <int NCT, int V> constexpr size_t dense_stage_lds_bytes() { return (size_t)2 * DenseGeom<float, NCT, V>::WAVES * DenseStage<NCT, V>::BYTES; }
 
 // Both tiles of a workgroup's knots [k_lo, k_lo + cnt) through the staging buffers (`stage`: dense_stage_lds_bytes of LDS, 16-byte
 // aligned; matrices 16-byte aligned): six stages (S: L D R, Pinv: L D R; three when P == nullptr), two in flight, alternating
@@ -234,30 +302,30 @@ __device__ __forceinline__ void dense_staged_load(const float *S, const float *P
     const uint32_t kw = k_lo + wave * Dg::BPW;
     const uint32_t nk = wave * Dg::BPW < cnt ? (cnt - wave * Dg::BPW < Dg::BPW ? cnt - wave * Dg::BPW : Dg::BPW) : 0u;
     const uint32_t kbase = kw < N ? kw : N - 1;
-    float *buf0 = stage + wave * kDenseStageFloats;
-    float *buf1 = buf0 + Dg::WAVES * kDenseStageFloats;
+    float *buf0 = stage + wave * DenseStage<NCT, V>::FLOATS;
+    float *buf1 = buf0 + Dg::WAVES * DenseStage<NCT, V>::FLOATS;
     const uint32_t lds0 = (uint32_t)(uintptr_t)buf0, lds1 = (uint32_t)(uintptr_t)buf1;
     const float *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
     const uint32_t b9 = dc.live ? lane / Dg::LPB : 0u;
-    dense_stage_issue(Sw, lane, nk, lds0);
-    dense_stage_issue(Sw + n * n, lane, nk, lds1);
+    dense_stage_issue<NCT, V>(Sw, lane, nk, lds0);
+    dense_stage_issue<NCT, V>(Sw + n * n, lane, nk, lds1);
     between();
-    dense_stage_wait<1>();
+    dense_stage_wait<NCT, V, 1>();
     dense_stage_pick<NCT, V, 0>(buf0, dc, b9, N, tS);
-    dense_stage_issue(Sw + 2 * n * n, lane, nk, lds0);
-    dense_stage_wait<1>();
+    dense_stage_issue<NCT, V>(Sw + 2 * n * n, lane, nk, lds0);
+    dense_stage_wait<NCT, V, 1>();
     dense_stage_pick<NCT, V, 1>(buf1, dc, b9, N, tS);
-    if (P) dense_stage_issue(Pw, lane, nk, lds1);
-    if (P) dense_stage_wait<1>(); else dense_stage_wait<0>();
+    if (P) dense_stage_issue<NCT, V>(Pw, lane, nk, lds1);
+    if (P) dense_stage_wait<NCT, V, 1>(); else dense_stage_wait<NCT, V, 0>();
     dense_stage_pick<NCT, V, 2>(buf0, dc, b9, N, tS);
     if (P) {
-        dense_stage_issue(Pw + n * n, lane, nk, lds0);
-        dense_stage_wait<1>();
+        dense_stage_issue<NCT, V>(Pw + n * n, lane, nk, lds0);
+        dense_stage_wait<NCT, V, 1>();
         dense_stage_pick<NCT, V, 0>(buf1, dc, b9, N, tP);
-        dense_stage_issue(Pw + 2 * n * n, lane, nk, lds1);
-        dense_stage_wait<1>();
+        dense_stage_issue<NCT, V>(Pw + 2 * n * n, lane, nk, lds1);
+        dense_stage_wait<NCT, V, 1>();
         dense_stage_pick<NCT, V, 1>(buf0, dc, b9, N, tP);
-        dense_stage_wait<0>();
+        dense_stage_wait<NCT, V, 0>();
         dense_stage_pick<NCT, V, 2>(buf1, dc, b9, N, tP);
     } else {
 #pragma unroll

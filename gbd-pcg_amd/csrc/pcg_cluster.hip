@@ -74,6 +74,7 @@ constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
 #ifndef GBDPCG_CL_PTAIL
 #define GBDPCG_CL_PTAIL 0   // columns of a lane's Pinv block-row kept in LDS instead of registers (0, 2, 4, ...): not needed since the kernel compiles without scratch; kept for A/B builds
 #endif
+template <int NCT> struct ClusterTail { static constexpr int COLS = NCT == 16 ? 16 : GBDPCG_CL_PTAIL; };
 #ifndef GBDPCG_CL_CHAINS
 #define GBDPCG_CL_CHAINS 3   // accumulator chains of a block-row product (bt_dense.hpp, dense_mv); 1 for A/B builds
 #endif
@@ -89,16 +90,21 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #endif
     constexpr uint32_t epoch_bits = kClEpochBits;
     using Dg = DenseGeom<float, NCT, V>;
-    static_assert(NCT == 14 && V == 2 && Dg::WAVES == 8, "lane roles below are written for 7 lanes x 2 rows per knot");
+    // lane roles below: n / 2 lanes x 2 rows per knot (a knot's boundary values are one 128-byte line of 16-byte granule pairs:
+    // n / 2 <= 8), 8 waves (lanes 4H..: partials of the 8 H waves, two per lane)
+    static_assert(V == 2 && NCT % 2 == 0 && NCT <= 16 && Dg::WAVES == 8, "lane roles below are written for n / 2 lanes x 2 rows per knot");
     constexpr uint32_t n = NCT, THREADS = Dg::WAVES * 64, WINF = align16<float>((Dg::MAX_KNOTS + 2) * n);
     __shared__ __attribute__((aligned(16))) float xa[WINF];   // window of p (lambda in the prologue): halo knot, own knots, halo knot
     __shared__ __attribute__((aligned(16))) float xb[WINF];   // window of r
     __shared__ float bc[4];       // [0] alpha / eta' of the phase just gathered, [1] beta
     __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out; [2], [3] the rescue's bookkeeping
     __shared__ float rescue_red[2 * Dg::WAVES];
-    // the last GBDPCG_CL_PTAIL columns of this lane's block-row of Pinv (two rows each): see dense_mv, TAIL
-    __shared__ __attribute__((aligned(16))) float2 ptail[(GBDPCG_CL_PTAIL ? GBDPCG_CL_PTAIL : 1) * THREADS];
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: dense_stage_lds_bytes (bt_dense.hpp)
+    // The last PTAIL columns of this lane's block-row of Pinv (two rows each) live in LDS instead of registers (dense_mv, TAIL):
+    // at n = 16 the whole R block of Pinv -- 2 x 96 matrix registers per lane do not fit next to the working set, 96 + 64 do.
+    // They take the place of the staging buffers once every wave's tiles are in (cluster_lds_bytes).
+    constexpr int PTAIL = ClusterTail<NCT>::COLS;
+    float2 *ptail = reinterpret_cast<float2 *>(stage_raw);
 
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -117,7 +123,6 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     const DenseCtx<float, NCT, V> dc(wave, lane, cnt, k_lo);
     // first of this lane's rows, counted from knot k_lo: (wave * 9 + lane / 7) * 14 + (lane % 7) * 2 = wave * 126 + 2 * lane
     const uint32_t row0 = dc.live ? wave * (Dg::BPW * n) + 2 * lane : 0u;
-    const size_t grow0 = (size_t)k_lo * n + row0;                     // ... in the problem's vectors
     // the same index inside a window, from an opaque copy of the lane number (see GBDPCG_CL_HANDOFF: not worth a register)
     auto own_idx = [&]() {
         uint32_t lo = lane;
@@ -359,11 +364,6 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
         }
 
-        if (P) {
-#pragma unroll
-            for (uint32_t t = 0; t < GBDPCG_CL_PTAIL; ++t)
-                ptail[t * THREADS + tid] = make_float2(tP.a[Dg::COLS - GBDPCG_CL_PTAIL + t][0], tP.a[Dg::COLS - GBDPCG_CL_PTAIL + t][1]);
-        }
         float rv[V], pv[V], yv[V];
         // windows: lambda on the own knots and the halos, zeros behind them (rows past the own knots, halos at the ends
         // of the problem); every entry has exactly one writer
@@ -376,9 +376,18 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             xa[i] = halo_lam;
             xb[i] = 0.f;
         }
-        for (uint32_t i = (cnt + 2) * n + tid; i < WINF; i += THREADS) xa[i] = xb[i] = 0.f;
+        {
+            uint32_t t = tid;
+            asm volatile("" : "+v"(t));
+            for (uint32_t i = (cnt + 2) * n + t; i < WINF; i += THREADS) xa[i] = xb[i] = 0.f;
+        }
         if (tid == 0) bci[0] = 0u;
         wg_barrier();
+        if (PTAIL > 0 && P) {   // (behind the barrier: every wave is done with its staging buffers, which this overwrites)
+#pragma unroll
+            for (int t = 0; t < PTAIL; ++t)
+                ptail[t * THREADS + tid] = make_float2(tP.a[Dg::COLS - PTAIL + t][0], tP.a[Dg::COLS - PTAIL + t][1]);
+        }
         GBDPCG_CL_STAMP_RT(16, 0, ordinal == 3)
 
         // r = gamma - S lambda                                            (pcg.cuh:118-126); the boundary knots of r travel
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
         float eta = 0.f;
         if (!failed) {
-            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, GBDPCG_CL_PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
+            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             wg_barrier();
             GBDPCG_CL_STAMP(5, POLL, iter == 3 && ordinal == 0)
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, GBDPCG_CL_PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
+            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
             part = 0.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -513,11 +522,16 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         GBDPCG_CL_STAMP_RT(19, 0, ordinal == 3)
         // outputs                                                         (pcg.cuh:212,215)
         if (dc.live && !failed) {
+            // (the row index from an opaque copy of the lane number: as three 64-bit addresses computed in front of the problem
+            // loop these were the kernel's last spills to scratch)
+            uint32_t lo = lane;
+            asm volatile("" : "+v"(lo));
+            const size_t g = voff + (size_t)k_lo * n + wave * (Dg::BPW * n) + 2 * lo;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                a.lambda[voff + grow0 + j] = lamv[j];
-                if (a.r) a.r[voff + grow0 + j] = rv[j];
-                if (a.p) a.p[voff + grow0 + j] = pv[j];
+                a.lambda[g + j] = lamv[j];
+                if (a.r) a.r[g + j] = rv[j];
+                if (a.p) a.p[g + j] = pv[j];
             }
         }
         if (h == 0 && tid == 0 && (!failed || a.rescue_off)) {
@@ -579,13 +593,23 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #undef GBDPCG_CL_STAMP_RT
 }
 
-// n = 14, fp32, general storage, 72 < N <= 288.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
+// The block sizes the kernel is built for (fp32, two rows per lane, n / 2 <= 8 lanes per knot; the staged tile loads want
+// n^2 % 4 == 0).  2 x 3n x 2 matrix registers per lane must leave room for the working set: at n = 16 (192) the R block of
+// Pinv stays in LDS (ClusterTail).
+#define GBDPCG_CLUSTER_N(X) X(8) X(10) X(12) X(14) X(16)
+
+// fp32, general storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n/2))
+// knots -- 72 at n = 14, 80 at n = 12) up to kClMaxH times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
 template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
 {
     static const bool off = getenv("GBDPCG_NO_CLUSTER") != nullptr;
-    if (off || sizeof(T) != 4 || n != 14) return 0;
-    constexpr uint32_t per_wg = DenseGeom<float, 14, 2>::MAX_KNOTS;
-    if (N <= per_wg) return 0;   // pcg_resident.hip has it in one workgroup
+    if (off || sizeof(T) != 4) return 0;
+    uint32_t per_wg = 0;
+#define GBDPCG_X(NN) \
+    if (n == NN) per_wg = DenseGeom<float, NN, 2>::MAX_KNOTS;
+    GBDPCG_CLUSTER_N(GBDPCG_X)
+#undef GBDPCG_X
+    if (per_wg == 0 || N <= per_wg) return 0;   // not built for the block size / pcg_resident.hip has it in one workgroup
     const uint32_t H = (N + per_wg - 1) / per_wg;
     return H <= kClMaxH ? H : 0;
 }
@@ -596,8 +620,15 @@ size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (s
 // Device memory for the in-kernel rescue: one set of vectors per cluster, sized for the longest horizon the path takes.
 size_t cluster_rescue_bytes(const DeviceInfo &dev)
 {
-    constexpr uint32_t per_wg = DenseGeom<float, 14, 2>::MAX_KNOTS;
-    return (size_t)(dev.num_cus / 2) * rescue_vec_elems<float>(14, kClMaxH * per_wg) * sizeof(float);
+    size_t elems = 0;
+#define GBDPCG_X(NN)                                                                                       \
+    {                                                                                                      \
+        const size_t e = rescue_vec_elems<float>(NN, kClMaxH * DenseGeom<float, NN, 2>::MAX_KNOTS);        \
+        elems = e > elems ? e : elems;                                                                     \
+    }
+    GBDPCG_CLUSTER_N(GBDPCG_X)
+#undef GBDPCG_X
+    return (size_t)(dev.num_cus / 2) * elems * sizeof(float);
 }
 
 template <typename T>
@@ -630,16 +661,25 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
         // coalesced LDS-DMA tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
         static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
         const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
-        auto kern = staged ? pcg_cluster_kernel<14, 2, true> : pcg_cluster_kernel<14, 2, false>;
-        const size_t lds = staged ? dense_stage_lds_bytes<14, 2>() : 0;
-        // on every launch, like the other launchers: HIP keeps the attribute per device
-        if (lds) {
-            *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (*err != hipSuccess) return true;
-        }
         static const bool no_plain = getenv("GBDPCG_CLUSTER_NO_PLAIN") != nullptr;   // tuning runs: always sc1 stores
-        hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, ka, static_cast<unsigned char *>(a.cluster_ws), H, C,
-                           clusters, spin_limit, drop_block, no_plain);
+        bool launched = false;
+#define GBDPCG_X(NN)                                                                                                     \
+        if (a.n == NN) {                                                                                                 \
+            auto kern = staged ? pcg_cluster_kernel<NN, 2, true> : pcg_cluster_kernel<NN, 2, false>;                     \
+            const size_t tail = (size_t)ClusterTail<NN>::COLS * 512 * sizeof(float2);                                   \
+            const size_t lds = staged ? (dense_stage_lds_bytes<NN, 2>() > tail ? dense_stage_lds_bytes<NN, 2>() : tail) : tail; \
+            /* on every launch, like the other launchers: HIP keeps the attribute per device */                          \
+            if (lds) {                                                                                                   \
+                *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (*err != hipSuccess) return true;                                                                     \
+            }                                                                                                            \
+            hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, ka, static_cast<unsigned char *>(a.cluster_ws), H, C, \
+                               clusters, spin_limit, drop_block, no_plain);                                              \
+            launched = true;                                                                                             \
+        }
+        GBDPCG_CLUSTER_N(GBDPCG_X)
+#undef GBDPCG_X
+        if (!launched) return false;
         *err = hipGetLastError();
         return true;
     } else {

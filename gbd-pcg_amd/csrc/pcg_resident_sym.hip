@@ -326,6 +326,17 @@ __device__ __forceinline__ void symres_dma_dword(const float *base, uint32_t off
                  : "=&s"(keep) : "s"(base), "v"(off), "s"(lds_addr) : "memory");
 }
 
+// Diagnostic build only (-DGBDPCG_RS_STAMPS, tools/rs_stamps.py): wave 0 of every workgroup leaves the 100 MHz real-time clock
+// at the phase boundaries of each of its problems in the handle's (otherwise unused here) cluster workspace: 8 stamps per
+// (workgroup, round).  No stamp exists in the shipped build.
+#ifdef GBDPCG_RS_STAMPS
+#define GBDPCG_RS_STAMP(IDX)                                                                                             \
+    if (tid == 0 && a.cluster_ws && rs_round < 8)                                                                        \
+        (reinterpret_cast<unsigned long long *>(a.cluster_ws) + 1024)[(blockIdx.x * 8 + rs_round) * 8 + (IDX)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GBDPCG_RS_STAMP(IDX)
+#endif
+
 template <int NCT, bool STAGED>
 __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 {
@@ -359,7 +370,14 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
     // which of this workgroup's problems this launch owns, 64 at a time (one memory round trip for all of them)
     unsigned long long takes = 0;
     uint32_t takes_from = 0;
+#ifdef GBDPCG_RS_STAMPS
+    uint32_t rs_round = 0xffffffffu;
+#endif
     for (uint32_t prob = blockIdx.x, pi = 0; prob < a.batch; prob += gridDim.x, ++pi) {
+#ifdef GBDPCG_RS_STAMPS
+        ++rs_round;
+#endif
+        GBDPCG_RS_STAMP(0)
         if (pi == 0 || pi - takes_from >= 64) {
             const uint32_t left = (a.batch - prob + gridDim.x - 1) / gridDim.x;
             takes = pcg_takes_mask(a, prob, gridDim.x, left < 64 ? left : 64u, lane);
@@ -422,6 +440,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             symres_stage_issue<NCT>(P, k0, g0, l8, sc);
             symres_stage_issue<NCT>(P, k1, g1, l8, sd);
             __builtin_amdgcn_sched_barrier(0);
+            GBDPCG_RS_STAMP(1)
             symres_stage_park<NCT>(sa, region, l8, g0, g0 && k0 != N - 1);
             symres_stage_pick<NCT>(region, rp, live0, s0);
             __builtin_amdgcn_sched_barrier(0);
@@ -459,6 +478,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         }
 #pragma unroll
         for (uint32_t i = 0; i < G::P0_LDS_QUADS; ++i) lt0[i * G::THREADS] = p0.q[i];
+        GBDPCG_RS_STAMP(2)
 
         for (uint32_t i = tid; i < n; i += G::THREADS) {
             xa[i] = 0.f; xa[n + len + i] = 0.f; xa[2 * n + len + i] = 0.f;
@@ -466,6 +486,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of lambda and gamma has landed in LDS
         __syncthreads();
+        GBDPCG_RS_STAMP(3)
 
         // One matrix-vector product over this lane's two block-rows.  XM: padded mirror of the operand.
         // Leaves y[1] complete and y[0] without the rows' share of R_{k0-1}^T x_{k0-1}, which the previous
@@ -555,6 +576,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 
         uint32_t iter = 0;
         bool max_iter_exit = true;
+        GBDPCG_RS_STAMP(4)
         for (; iter < a.max_iter; ++iter) {                               // pcg.cuh:154
             GBDPCG_SYMRES_PREFETCH()
             // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
@@ -595,6 +617,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
 #undef GBDPCG_SYMRES_MV
 #undef GBDPCG_SYMRES_FINISH_Y
 
+        GBDPCG_RS_STAMP(5)
         while (pf < pf_per_matrix) { GBDPCG_SYMRES_PREFETCH() }  // short solves: the rest of the prefetch
 #undef GBDPCG_SYMRES_PREFETCH
 
@@ -610,6 +633,7 @@ __global__ __launch_bounds__(512) void pcg_resident_sym_kernel(PcgArgs<float> a)
             if (a.max_iter_exit) a.max_iter_exit[prob] = max_iter_exit ? 1 : 0;
         }
         __syncthreads();  // LDS (tile, vectors) is reused by the next problem
+        GBDPCG_RS_STAMP(6)
     }
     // The prefetch loads are invisible to the compiler's counters; s_endpgm drains the wave's memory counters in
     // hardware, and this makes it explicit: none of them can still be in flight (towards this workgroup's LDS dump

@@ -78,6 +78,14 @@ def test_cluster_shapes(solver):
     assert solver.cluster_members(4, 14, 72) == 0      # one workgroup holds it (pcg_resident.hip)
     assert solver.cluster_members(4, 14, 289) == 0 and solver.cluster_members(8, 14, 128) == 0
     assert solver.cluster_members(4, 36, 128) == 0
+    # stateSize 12 (round 3): 80 knots per workgroup
+    assert solver.cluster_members(4, 12, 80) == 0 and solver.cluster_members(4, 12, 81) == 2 and solver.cluster_members(4, 12, 128) == 2
+    assert solver.cluster_members(4, 12, 161) == 3 and solver.cluster_members(4, 12, 320) == 4 and solver.cluster_members(4, 12, 321) == 0
+    assert solver.cluster_members(8, 12, 128) == 0 and solver.cluster_members(4, 13, 128) == 0 and solver.cluster_members(4, 18, 128) == 0
+    # ... 8, 10 and 16: 128, 96 and 64 knots per workgroup
+    assert solver.cluster_members(4, 8, 128) == 0 and solver.cluster_members(4, 8, 256) == 2 and solver.cluster_members(4, 8, 512) == 4
+    assert solver.cluster_members(4, 10, 96) == 0 and solver.cluster_members(4, 10, 128) == 2
+    assert solver.cluster_members(4, 16, 64) == 0 and solver.cluster_members(4, 16, 128) == 2 and solver.cluster_members(4, 16, 256) == 4
 
 
 @pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (73, 2), (100, 9), (144, 3), (145, 2), (200, 4), (216, 1), (217, 2), (288, 3)])
@@ -88,6 +96,30 @@ def test_cluster_vs_oracle(solver, orc, N, B):
     ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
     out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"])
     check(out, ob, d, B)
+
+
+@pytest.mark.parametrize("n,N,B", [(12, 128, 5), (12, 81, 3), (12, 100, 140), (12, 160, 2), (12, 161, 3), (12, 240, 70), (12, 320, 2),
+                                   (12, 319, 1), (8, 129, 3), (8, 256, 70), (8, 300, 2), (8, 512, 1), (10, 97, 2), (10, 128, 140), (10, 200, 3),
+                                   (10, 384, 2), (16, 65, 2), (16, 128, 140), (16, 129, 3), (16, 200, 70), (16, 256, 2)])
+def test_cluster_other_state_sizes(solver, orc, n, N, B):
+    """The same kernel at stateSize 8, 10, 12 and 16 (n / 2 lanes per knot, 128 / 96 / 80 / 64 knots per workgroup; at 16 the R
+    block of Pinv stays in LDS): two, three and four workgroups per problem, ragged splits, more problems
+    than one round of clusters -- in general storage and, since symmetric STREAMING is slower than general RESIDENT, in the
+    default symmetric mode as well."""
+    base = min(B, 6)
+    d = synth.gen_numpy(n, N, seed=700 + N, batch=base, dtype=np.float32)
+    idx = np.arange(B) % base
+    S, Pi = d["S"][idx], d["Pinv"][idx]
+    g = (d["gamma"][idx] * (1.0 + 0.01 * (np.arange(B) // base))[:, None]).astype(np.float32)
+    ob = orc.pcg_batch(n, N, B, S, Pi, g, tol=1e-6, max_iter=100, nthreads=8)
+    for mode in (0, 2):
+        out = run(solver, n, N, B, S, Pi, g, symmetric=mode)
+        check(out, ob, {"gamma": g}, B)
+    # fixed count, warm start: lambda, r and p after exactly 5 iterations
+    lam0 = (0.1 * np.random.default_rng(N).standard_normal((B, n * N))).astype(np.float32)
+    ob = orc.pcg_batch(n, N, B, S, Pi, g, tol=0.0, max_iter=5, lambda0=lam0, nthreads=8)
+    out = run(solver, n, N, B, S, Pi, g, lam0=lam0, tol=0.0, max_iter=5)
+    check(out, ob, {"gamma": g}, B, ltol=2e-6)
 
 
 @pytest.mark.parametrize("N,B", [(250, 70), (150, 100), (288, 64), (100, 130)])
