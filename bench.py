@@ -61,7 +61,7 @@ def profile_json(name):
 def pmc_traffic(kernel_prefix):
     """HBM-side bytes per launch from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
     same benchmark, gfx950 x2 read correction calibrated on known-size reads).  None when no profile matches."""
-    for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         prof = profile_json(f)
         if not prof:
             continue
@@ -73,7 +73,7 @@ def pmc_traffic(kernel_prefix):
 
 def schur_traffic(kernel):
     """HBM-side bytes per launch of a schur.hip kernel from the committed PMC passes of tools/schur_run.py."""
-    prof = profile_json("r02_schur_kernels.json")
+    prof = profile_json("r03_schur_kernels.json") or profile_json("r02_schur_kernels.json")
     rec = (prof or {}).get("kernels", {}).get(kernel)
     return rec.get("traffic_bytes_per_launch") if rec else None
 
@@ -81,7 +81,7 @@ def schur_traffic(kernel):
 def pmc_valu(kernel_prefix):
     """VALU-issue utilisation of a kernel from the committed SQ-counter pass (profiles/r02_pmc_sq.json, written by
     gbd-pcg_amd/tools/pmc_sq_json.py): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES per SIMD, LDS bank-conflict share."""
-    prof = profile_json("r02_pmc_sq.json")
+    prof = profile_json("r03_pmc_sq.json") or profile_json("r02_pmc_sq.json")
     if not prof:
         return None
     for name, rec in prof.get("kernels", {}).items():
@@ -418,6 +418,20 @@ def run_rank(args, world, rank, local_rank):
                      and int(solver.check_symmetric(n, N, B, P).min()) == 1)
     REPS = max(100, args.steps)
     sym_ms, sym_best, sym_ver = time_mode(1, REPS)   # the dominant kernel alone (caller asserts symmetry: no check launch)
+
+    def time_converged(mode, reps):
+        """The same kernel run to exit_tol = 1e-6 (what an MPC loop runs: 9 iterations on this generator)."""
+        solver.set_symmetric(mode)
+        gr = solver.graph_solve(n, N, B, S, P, gamma, lam, r, p, 1e-6, iters, it_out, fl_out)
+        solver.set_symmetric(2)
+        med, best = time_graph(gr, reps)
+        ver = verify_solve(solver, torch, n, N, B, S, gamma, lam, it_out, fl_out, "converged")
+        mean_it = float(it_out.float().mean())
+        gr.close()
+        return med, best, ver, mean_it
+
+    conv_ms, conv_best, conv_ver, conv_it = time_converged(1, REPS)
+    dflt_ms, _, dflt_ver, _ = time_converged(2, REPS)
     flops = pcg_flops_per_launch(n, N, B, iters)
     pcg_bytes = pcg_bytes_per_launch(n, N, B, iters, 4)
     resident_bytes = B * (2 * (2 * N - 1) * n * n + 5 * n * N) * 4   # [D|R] of both matrices once per solve + vectors
@@ -476,6 +490,19 @@ def run_rank(args, world, rank, local_rank):
                                                    "what a streaming kernel would have to sustain to match; not an HBM rate"},
                 "all_problems_symmetric": all_symmetric,
                 "verified": sym_ver,
+                "converged": {"bound": "per-CU ingest (fabric), then valu", "exit_tol": 1e-6, "iters_mean": conv_it,
+                              "kernel_ms": conv_ms, "kernel_ms_min": conv_best,
+                              "default_path_ms_incl_symmetry_check": dflt_ms,
+                              "solves_per_sec_one_gpu": B / (conv_ms * 1e-3),
+                              "achieved": resident_bytes / (conv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": resident_bytes / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "bytes_moved_per_launch": resident_bytes,
+                              "tflops": pcg_flops_per_launch(n, N, B, conv_it) / (conv_ms * 1e-3) / 1e12,
+                              "frac_of_fp32_peak": pcg_flops_per_launch(n, N, B, conv_it) / (conv_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                              "verified": conv_ver, "verified_default_path": dflt_ver,
+                              "note": "the number an MPC loop sees: the solve stops at |r.Pinv r| < 1e-6; per round of 256 problems "
+                                      "about 17 us are tile loads at the per-CU ingest rate (401 KB at ~33 GB/s per CU, "
+                                      "profiles/r03_resident_stamps.txt) + prologue + write-back, the rest 2.2 us per iteration"},
                 "note": "peak = fp32 vector peak (= dense fp32 MFMA peak) of MI355X_MICROARCH.md; the matrices are read once "
                         "per solve, so the kernel is bound by VALU issue and on-chip latency, not by HBM"},
             "pinv_onchip": {"hit_rate": iters / (iters + 1.0), "from_lds": lds_share, "from_registers": 1.0 - lds_share,

@@ -18,6 +18,7 @@ MAT = 3 * N_ * N_ * KNOTS * 4 * BATCH               # one matrix of the batch, f
 ALG_SPMV = ((3 * KNOTS - 2) * N_ * N_ + 2 * N_ * KNOTS) * 4 * BATCH
 ALG_PCG = BATCH * ((2 * ITERS + 2) * (3 * KNOTS - 2) * N_ * N_ + 5 * N_ * KNOTS) * 4
 SYM_ONCE = BATCH * (2 * (2 * KNOTS - 1) * N_ * N_ + 5 * N_ * KNOTS) * 4   # [D|R] of S and Pinv read once per solve
+FULL_ONCE = BATCH * (2 * 3 * KNOTS * N_ * N_ + 5 * N_ * KNOTS) * 4         # [L|D|R] of S and Pinv read once per solve
 
 
 def per_kernel(root, counter):
@@ -60,6 +61,7 @@ def main():
             res["calibration"][name] = {"known_bytes": MAT, "FETCH_SIZE_KiB": sum(v) / len(v),
                                         "ratio": sum(v) / len(v) * 1024 / MAT, "dispatches": len(v)}
     table = [("pcg_resident_sym_kernel", "pcg_resident_sym_kernel<14,true> (config 3, 25 iterations, matrices resident on the CU)", ALG_PCG, SYM_ONCE),
+             ("pcg_cluster_kernel<14", "pcg_cluster_kernel<14,2,true> (config 3, 25 iterations, general storage resident over two CUs per problem)", ALG_PCG, FULL_ONCE),
              ("pcg_fused_kernel<float, 14, 2, 8, false>", "pcg_fused_kernel<float,14,2,8,false> (config 3, 25 iterations, general)", ALG_PCG, ALG_PCG),
              ("check_symmetric_pair_kernel", "check_symmetric_pair_kernel<float> (config 3, S and Pinv)", None, 2 * BATCH * (KNOTS - 1) * 2 * N_ * N_ * 4),
              ("spmv_kernel<float, 14", "spmv_kernel<float,14,2,4> (config 3)", ALG_SPMV, ALG_SPMV),

@@ -116,6 +116,15 @@ def main():
                 f.write("# gbd-pcg_amd/examples/kkt_step_loop 1024 128 20 under rocprofv3 --kernel-trace (one graph replay per step: KKT blocks -> S, gamma,\n"
                         "# G^-1 -> stair Pinv -> PCG to |eta| < 1e-10, warm-started -> primal step; KKT residuals checked in fp64 on the host)\n")
                 f.write(open(lp).read())
+    for name, dstname, head in (("resident_stamps.txt", "resident_stamps.txt",
+                                 "# gbd-pcg_amd/tools/rs_stamps.py (diagnostic build -DGBDPCG_RS_STAMPS: stamps in the loop, iterations ~20 % slower than shipped):\n"
+                                 "# median over the 256 workgroups of the time between phase boundaries of each round, us (100 MHz real-time clock)\n"),
+                                ("solve_shapes.jsonl", "solve_shapes.jsonl", ""), ("ab_pinv.txt", "pinv_ab_latest.txt", "")):
+        sp = os.path.join(src, name)
+        if os.path.exists(sp) and os.path.getsize(sp) > 0:
+            body = "".join(ln for ln in open(sp) if "amdgpu.ids" not in ln)
+            with open(os.path.join(dst, f"{rnd}_{dstname}"), "w") as f:
+                f.write(head + body)
     # SQ counters
     out = {"_how": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU "
                    "SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE on `bench.py --steps 3 --warmup 1` "

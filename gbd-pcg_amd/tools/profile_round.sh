@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything profiles/rNN_* is derived from, in one GPU-box call (run from the repo root):
-#   bash gbd-pcg_amd/tools/profile_round.sh r02
+#   bash gbd-pcg_amd/tools/profile_round.sh r03
 # rocprofv3 passes of bench.py (kernel stats; FETCH_SIZE, WRITE_SIZE and SQ counters in separate --pmc passes, each with
 # --kernel-trace only) and of the bandwidth probe that calibrates FETCH_SIZE on reads of known size.  Raw output goes to
 # gpurun_out/prof_<round>/ ; gbd-pcg_amd/tools/profile_digest.py turns it into the files committed under profiles/.
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -65,6 +65,14 @@ echo "[12] the whole inner step as one graph (examples/kkt_step_loop): which ker
 if [ -x $ROOT/gbd-pcg_amd/examples/kkt_step_loop ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kkt_stats -- $ROOT/gbd-pcg_amd/examples/kkt_step_loop 1024 128 20 > $OUT/kkt_step_loop.txt 2> $OUT/kkt_stats.log || { tail -5 $OUT/kkt_stats.log; exit 1; }
 fi
+echo "[13] phase stamps of a round of the resident symmetric kernel (diagnostic build, if present)"
+if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_rsstamps.so ]; then
+  GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_rsstamps.so python3 $ROOT/gbd-pcg_amd/tools/rs_stamps.py > $OUT/resident_stamps.txt 2>/dev/null || true
+fi
+echo "[14] converged / fixed-count solves by shape on the default path (solve_shapes.py)"
+python3 $ROOT/gbd-pcg_amd/tools/solve_shapes.py 14,128,1024,f32 12,128,1024,f32 16,128,1024,f32 10,128,1024,f32 8,256,1024,f32 13,128,1024,f32 18,128,1024,f32 14,128,1024,f64 14,256,64,f32 14,64,1,f32 36,256,1,f64 > $OUT/solve_shapes.jsonl 2>/dev/null || true
+echo "[15] the stair kernel: fp32 MFMA + one LDS-DMA request per workgroup against the VALU kernel (ab_pinv.py)"
+python3 $ROOT/gbd-pcg_amd/tools/ab_pinv.py > $OUT/ab_pinv.txt 2>/dev/null || true
 [ -x $ROOT/gbd-pcg_amd/tools/bin/hop_probe ] && $ROOT/gbd-pcg_amd/tools/bin/hop_probe > $OUT/hop_probe.txt 2>/dev/null || true
 # keep what the digest needs, drop the bulky traces
 find $OUT -name "*.db" -delete 2>/dev/null
