@@ -785,6 +785,9 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
     }
 }
 
+// (Used for stateSize 16, where the VALU products of the kernel above are the bound: 264 -> 180 us per 1024 x 128 knots.  At 14 and
+// 12 the two kernels tie within the box-to-box spread -- neither is bound by its vector work there -- and the older kernel stays.
+// GBDPCG_PINV_MFMA_FROM=<n> moves the threshold for A/B runs.)
 // The one-launch stair for fp32, rebuilt around what the counters of the kernel above say (profiles/r03_pinv_ab.txt): it ran at
 // half the HBM rate with NOTHING saturated -- vector pipes 47-64 % busy, LDS 28 %, 14 GB/s per compute unit -- because every wave
 // walks a chain of dependent round trips (D blocks in, eliminate, then four pairs: R / L in, two products, results out) with a
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t
 //     k order (Dk1^-1 is mirrored exactly), so R'_k and L'_{k+1} are bit-for-bit transposes whenever S was: the property the
 //     symmetric solve kernels rely on.
 // Pass 1 (the inversions) is the DPP Gauss-Jordan of the kernel above; so are the verdict bytes and S_SYM.  S must be 16-byte
-// aligned (the launcher checks).  52 KB of LDS per workgroup: three workgroups per compute unit.
+// aligned (the launcher checks).  54 KB of LDS per workgroup (n = 14): three workgroups per compute unit.
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
 typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -815,12 +818,12 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_mfma_kernel(uint32_t 
                                                                       float *__restrict__ Pinv, uint8_t *__restrict__ verdicts)
 {
     constexpr bool s_symmetric = S_SYM;
-    constexpr uint32_t n = NCT, nn = n * n, PAIRS = 15, LD = 16, IMG = LD * LD;
+    constexpr uint32_t n = NCT, nn = n * n, PAIRS = 15, LD = 20, IMG = n * LD;   // images: n rows of 20 floats (16 used: 64-bank-friendly stride)
     static_assert(n <= 16 && n % 2 == 0, "quarter-wave elimination, 16 x 16 MFMA images, 16-byte blocks");
     constexpr uint32_t RAW = 46 * nn;                                  // D_k0 .. D_k0+15 with the R / L blocks between them
     constexpr uint32_t PIECES = RAW / 4, ROUNDS = (PIECES + kPinvThreads - 1) / kPinvThreads;   // 16-byte pieces, per-thread rounds
-    __shared__ __attribute__((aligned(16))) float raw[ROUNDS * kPinvThreads * 4 + 8];   // (+8: the k = 14, 15 over-read of the last block)
-    __shared__ __attribute__((aligned(16))) float inv[16][IMG];        // mirrored D^-1 of knots k0 .. k0+15, (r, c) at r * 16 + c
+    __shared__ __attribute__((aligned(16))) float raw[RAW + 8];        // (+8: the k = 14, 15 over-read of the last block)
+    __shared__ __attribute__((aligned(16))) float inv[16][IMG];        // mirrored D^-1 of knots k0 .. k0+15, (r, c) at r * 20 + c
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u, quarter = lane >> 4, l = lane & 15u;
     const uint32_t prob = blockIdx.x / chunks, chunk = blockIdx.x - prob * chunks;
     const uint32_t k0 = chunk * PAIRS;
@@ -836,11 +839,13 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_mfma_kernel(uint32_t 
             const uint32_t piece = rd * kPinvThreads + wave * 64 + lane;
             const uint32_t off = (piece < have ? piece : have - 1u) * 16u;
             const uint32_t dst = (uint32_t)(uintptr_t)raw + (rd * kPinvThreads + wave * 64) * 16u;   // wave-uniform; the lane's 16 bytes follow
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(src), "v"(off), "s"(dst) : "memory");
+            if (piece < PIECES) {   // (lanes past the run are masked off: an inactive lane of an LDS-DMA writes nothing)
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "s"(src), "v"(off), "s"(dst) : "memory");
+            }
         }
-        if (threadIdx.x < 8) raw[ROUNDS * kPinvThreads * 4 + threadIdx.x] = 0.f;
+        if (threadIdx.x < 8) raw[RAW + threadIdx.x] = 0.f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -863,14 +868,11 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_mfma_kernel(uint32_t 
             for (uint32_t r = 0; r < n; ++r)
                 if (r < l) inv[slot][r * LD + l] = col[r];        // its mirror image: (l, r) := (r, l)
         }
-        // zero pads: rows / columns n .. 15 of the image (what they meet in the other operand is finite, so the sum is exact)
-        if constexpr (n < LD) {
-            if (l >= n) {
+        // zero pads: columns n .. 15 of the image (what they meet in the other operand is finite, so the sum is exact)
+        if constexpr (n < 16) {
+            if (owner) {
 #pragma unroll
-                for (uint32_t r = 0; r < LD; ++r) inv[slot][l * LD + r] = 0.f;
-            } else {
-#pragma unroll
-                for (uint32_t c = n; c < LD; ++c) inv[slot][l * LD + c] = 0.f;
+                for (uint32_t c = n; c < 16; ++c) inv[slot][l * LD + c] = 0.f;
             }
         }
     }
@@ -926,8 +928,8 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_mfma_kernel(uint32_t 
                 }
             }
         }
-        const mf_f32x4 a4 = *reinterpret_cast<const mf_f32x4 *>(A + l * LD + 4 * quarter);   // Dk^-1 (4q + kk, l), symmetric
-        const mf_f32x4 c4 = *reinterpret_cast<const mf_f32x4 *>(C + l * LD + 4 * quarter);   // Dk1^-1 (l, 4q + kk) = (4q + kk, l)
+        const mf_f32x4 a4 = *reinterpret_cast<const mf_f32x4 *>(A + lc * LD + 4 * quarter);   // Dk^-1 (4q + kk, l), symmetric
+        const mf_f32x4 c4 = *reinterpret_cast<const mf_f32x4 *>(C + lc * LD + 4 * quarter);   // Dk1^-1 (l, 4q + kk) = (4q + kk, l)
         for (int pass = 0; pass < (symmetric ? 1 : 2); ++pass) {
             mf_f32x4 b4;   // B(4q + kk, l): B = R_k, then (asymmetric pair) L_{k+1}^T
             if (pass == 0) {
@@ -1138,9 +1140,10 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
                 const uint32_t chunks = pinv_verdict_chunks<T>(n, N, kind);                                          \
                 if (chunks) {                                                                                        \
                     if ((uint64_t)chunks * batch > 0x7fffffffull) return hipErrorInvalidValue;                       \
-                    if constexpr (sizeof(T) == 4 && NN >= 14) {   /* measured: -6 % at 14, -32 % at 16, slower at 8 and 12 */  \
+                    if constexpr (sizeof(T) == 4 && NN >= 12) {   /* measured: -32 % at 16; a tie at 14 and 12 (profiles/r03_pinv_ab.txt) */ \
                         static const bool no_mfma = getenv("GBDPCG_PINV_NO_MFMA") != nullptr; /* tuning runs only */ \
-                        if (!no_mfma && reinterpret_cast<uintptr_t>(S) % 16 == 0) {   /* (LDS-DMA in 16-byte pieces) */ \
+                        static const int mfma_from = [] { const char *e = getenv("GBDPCG_PINV_MFMA_FROM"); return e ? atoi(e) : 16; }(); \
+                        if (!no_mfma && (int)NN >= mfma_from && reinterpret_cast<uintptr_t>(S) % 16 == 0) {   /* (LDS-DMA in 16-byte pieces) */ \
                             const dim3 grid(chunks * batch);                                                         \
                             if (s_symmetric)                                                                         \
                                 hipLaunchKernelGGL((pinv_stair_mfma_kernel<NN, true>), grid, dim3(kPinvThreads), 0, s, N, chunks, \
