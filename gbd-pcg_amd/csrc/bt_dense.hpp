@@ -75,14 +75,23 @@ __device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, 
 // TAIL > 0 (CHAINS = 3 only): the last TAIL columns of the block-row are not in the tile but in LDS, `tail[t * tstride]` =
 // this lane's two rows of column COLS - TAIL + t (a deliberate, cheap spill: pcg_cluster.hip keeps 8 of its 168 matrix
 // registers there, because hipcc otherwise spills a few of them to scratch and reloads them inside every product).
+// A lane's V rows of one tail column as they lie in LDS: a pair (V = 2) or a single value (V = 1).
+template <typename T, int V> struct DenseTailElem { using type = typename VecOf<T, 2>::type; };
+template <typename T> struct DenseTailElem<T, 1> { using type = T; };
+__device__ __forceinline__ float dense_tail_row(const float &v, int) { return v; }
+__device__ __forceinline__ double dense_tail_row(const double &v, int) { return v; }
+__device__ __forceinline__ float dense_tail_row(const float2 &v, int j) { return j == 0 ? v.x : v.y; }
+__device__ __forceinline__ double dense_tail_row(const double2 &v, int j) { return j == 0 ? v.x : v.y; }
+
 template <typename T, int NCT, int V, int CHAINS = 1, int TAIL = 0>
 __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T *X, const DenseCtx<T, NCT, V> &dc,
-                                         T (&acc)[V], const typename VecOf<T, 2>::type *tail = nullptr, uint32_t tstride = 0)
+                                         T (&acc)[V], const typename DenseTailElem<T, V>::type *tail = nullptr, uint32_t tstride = 0)
 {
     using Dg = DenseGeom<T, NCT, V>;
     using P2 = typename VecOf<T, 2>::type;
+    using TV = typename DenseTailElem<T, V>::type;
     static_assert(CHAINS == 1 || (CHAINS == 3 && Dg::N_ % 2 == 0), "one chain, or one per block (whole x pairs per block)");
-    static_assert(TAIL == 0 || (CHAINS == 3 && V == 2 && TAIL % 2 == 0 && TAIL <= (int)Dg::N_), "tail columns: whole pairs of the last block");
+    static_assert(TAIL == 0 || (CHAINS == 3 && V <= 2 && TAIL % 2 == 0 && TAIL <= (int)Dg::N_), "tail columns: whole pairs of the last block");
     const uint32_t kl = dc.live ? dc.kl : 0u;
     const P2 *xk = reinterpret_cast<const P2 *>(X + kl * Dg::N_);  // column c of local row kl multiplies X[kl*n + c]
     T part[CHAINS][V];
@@ -90,7 +99,18 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
     for (int q = 0; q < CHAINS; ++q)
 #pragma unroll
         for (int j = 0; j < V; ++j) part[q][j] = T(0);
-    if constexpr (CHAINS == 1) {
+    if constexpr (CHAINS == 1 && Dg::COLS % 2 != 0) {
+        // odd block size: the operand pairs of a knot are not 8-byte aligned in the window; one entry per read
+        const T *x1 = X + kl * Dg::N_;
+#pragma unroll
+        for (uint32_t c = 0; c < Dg::COLS; ++c) {
+            const T xv = x1[c];
+#pragma unroll
+            for (int j = 0; j < V; ++j) part[0][j] = fma_t(tl.a[c][j], xv, part[0][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = part[0][j];
+    } else if constexpr (CHAINS == 1) {
 #pragma unroll
         for (uint32_t c = 0; c < Dg::COLS; c += 2) {
             const P2 xv = xk[c / 2];
@@ -105,7 +125,8 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
         // The three blocks side by side: independent work in every step.  The steps are pinned in source order with the
         // operands of the next one requested before the fma's of this one: left to itself hipcc hoists all 21 operand reads
         // to the top (42 more live registers next to 168 of matrix data) and spills elsewhere in the kernel.
-        P2 xv[3], nx[3], tv[2], nt[2];
+        P2 xv[3], nx[3];
+        TV tv[2], nt[2];
 #pragma unroll
         for (int q = 0; q < 3; ++q) xv[q] = xk[(q * Dg::N_) / 2];
         if constexpr (TAIL >= (int)Dg::N_) {
@@ -129,14 +150,23 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
                 const bool from_lds = TAIL > 0 && q == 2 && c >= Dg::N_ - TAIL;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const T m = from_lds ? (j == 0 ? tv[0].x : tv[0].y) : tl.a[q * Dg::N_ + c][j];
+                    const T m = from_lds ? dense_tail_row(tv[0], j) : tl.a[q * Dg::N_ + c][j];
                     part[q][j] = fma_t(m, xv[q].x, part[q][j]);
                 }
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const T m = from_lds ? (j == 0 ? tv[1].x : tv[1].y) : tl.a[q * Dg::N_ + c + 1][j];
+                    const T m = from_lds ? dense_tail_row(tv[1], j) : tl.a[q * Dg::N_ + c + 1][j];
                     part[q][j] = fma_t(m, xv[q].y, part[q][j]);
                 }
+            }
+            if constexpr (TAIL > 0 || sizeof(T) == 8) {
+                // with tail operands coming out of LDS (and in fp64, where everything is twice as wide) the accumulators are anchored here as well: the sched_barrier alone orders
+                // the LDS reads, and hipcc then sinks every fma of the product below the last of them (all operands live at
+                // once: 80 registers, and matrix registers spilled inside the iteration)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) asm volatile("" : "+v"(part[q][j]));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -149,39 +179,40 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
     }
 }
 
-// Staged tile loads (fp32, V = 2, even n with n^2 % 4 == 0).  A wave's knots are contiguous in memory; one block (L, D or R:
-// n^2 floats = n^2 / 4 pieces of 16 bytes) of each of its up to BPW knots is fetched per stage with LOADS LDS-DMA instructions
-// (64 lanes x 16 bytes, dense and coalesced, no VGPR in between; n = 14: 9 knots x 49 pieces, 7 instructions) into the wave's
-// own staging buffer, and the lanes then pick their two rows up with 8-byte LDS reads.  The direct form (dense_load above)
-// reads 8 bytes per lane at an n-float stride: 6 n sparse instructions per matrix, bound by the address path -- in
-// pcg_cluster.hip 28 us of a 40 us round went there.
-template <int NCT, int V> struct DenseStage {
-    using Dg = DenseGeom<float, NCT, V>;
-    static constexpr uint32_t PIECES = NCT * NCT / 4;                            // 16-byte pieces per n x n block
+// Staged tile loads (a lane's V rows of a column are 8 bytes: fp32 with V = 2 or fp64 with V = 1; whole 16-byte pieces per block).
+// A wave's knots are contiguous in memory; one block (L, D or R: n^2 elements) of each of its up to BPW knots is fetched per
+// stage with LOADS LDS-DMA instructions (64 lanes x 16 bytes, dense and coalesced, no VGPR in between; n = 14, fp32: 9 knots x
+// 49 pieces, 7 instructions) into the wave's own staging buffer, and the lanes then pick their rows up with 8-byte LDS reads.
+// The direct form (dense_load above) reads 8 bytes per lane at an n-element stride: 6 n sparse instructions per matrix, bound
+// by the address path -- in pcg_cluster.hip 28 us of a 40 us round went there.
+template <typename T, int NCT, int V> struct DenseStage {
+    using Dg = DenseGeom<T, NCT, V>;
+    static constexpr bool OK = V * sizeof(T) == 8 && (NCT * NCT * sizeof(T)) % 16 == 0;
+    static constexpr uint32_t PIECES = NCT * NCT * sizeof(T) / 16;               // 16-byte pieces per n x n block
     static constexpr uint32_t LOADS = (Dg::BPW * PIECES + 63) / 64;              // LDS-DMA instructions per stage
-    static constexpr uint32_t BYTES = LOADS * 64 * 16, FLOATS = BYTES / 4;       // one staging buffer of one wave
-    static_assert(V == 2 && NCT % 2 == 0 && (NCT * NCT) % 4 == 0, "whole 16-byte pieces per block, two rows per lane");
-    static_assert(LOADS >= 1 && LOADS <= 8, "a stage is counted on vmcnt");
+    static constexpr uint32_t BYTES = LOADS * 64 * 16;                           // one staging buffer of one wave
+    static constexpr uint32_t BLOCK_ROW_BYTES = 3 * NCT * NCT * sizeof(T);
 };
 
 // Issue one stage: lane l of instruction i moves the 16-byte piece q = 64 i + l of the wave's `nk` blocks (PIECES each, blocks
-// 3 n^2 floats apart) from base to lds_addr + 16 q.  Lanes beyond the last piece re-read piece 0 into slots nobody picks
+// one block-row apart) from base to lds_addr + 16 q.  Lanes beyond the last piece re-read piece 0 into slots nobody picks
 // up: every lane of every instruction is live, so a stage is always exactly LOADS loads on the wave's counter.  The offsets
 // are recomputed from the lane number at every issue (kept in registers across the stages they were spilled, and every
 // reload from scratch came with an s_waitcnt vmcnt(0) that drained the stages in flight).  The loads are written in asm
 // (M0 carries the LDS address) and so are invisible to hipcc's counters: the caller waits with dense_stage_wait before
 // it reads the buffer, and never has more than two stages in flight.
-template <int NCT, int V>
-__device__ __forceinline__ void dense_stage_issue(const float *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
+template <typename T, int NCT, int V>
+__device__ __forceinline__ void dense_stage_issue(const T *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
 {
-    using St = DenseStage<NCT, V>;
+    using St = DenseStage<T, NCT, V>;
+    static_assert(St::OK && St::LOADS >= 4 && St::LOADS <= 8, "stage sizes written out: 4 .. 8 loads");
     uint32_t lo = lane;
     asm volatile("" : "+v"(lo));
     uint32_t rel[St::LOADS];
 #pragma unroll
     for (uint32_t i = 0; i < St::LOADS; ++i) {
         const uint32_t q = i * 64 + lo, j = q / St::PIECES;   // (a constant divisor: multiply and shift)
-        rel[i] = j < nk ? q * 16 + j * (3 * NCT * NCT * 4 - St::PIECES * 16) : 0u;
+        rel[i] = j < nk ? q * 16 + j * (St::BLOCK_ROW_BYTES - St::PIECES * 16) : 0u;
     }
     unsigned keep;
     // ONE asm statement per stage: M0 must not be touched by anything the compiler schedules in between
@@ -255,81 +286,104 @@ __device__ __forceinline__ void dense_stage_issue(const float *base, uint32_t la
                      : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "v"(rel[7]), "s"(lds_addr)
                      : "memory", "scc");
     }
-    else static_assert(St::LOADS >= 4 && St::LOADS <= 8, "stage sizes written out: 4 .. 8 loads");
 }
 // all but the youngest `newer` stages (LOADS loads each) of this wave have landed
-template <int NCT, int V, int NEWER> __device__ __forceinline__ void dense_stage_wait()
+template <typename T, int NCT, int V, int NEWER> __device__ __forceinline__ void dense_stage_wait()
 {
     if constexpr (NEWER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DenseStage<NCT, V>::LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DenseStage<T, NCT, V>::LOADS) : "memory");
 }
 
 typedef float2 __attribute__((may_alias)) dense_float2_alias;
 
-// This lane's two rows of block BLK (0 = L, 1 = D, 2 = R) out of the wave's staging buffer into its tile.
-template <int NCT, int V, int BLK>
-__device__ __forceinline__ void dense_stage_pick(const float *buf, const DenseCtx<float, NCT, V> &dc, uint32_t b9, uint32_t N,
-                                                   DenseTile<float, NCT, V> &tl)
+// This lane's V rows (8 bytes per column) of block BLK (0 = L, 1 = D, 2 = R) out of the wave's staging buffer into its tile.
+template <typename T, int NCT, int V, int BLK>
+__device__ __forceinline__ void dense_stage_pick(const unsigned char *buf, const DenseCtx<T, NCT, V> &dc, uint32_t b9, uint32_t N,
+                                                   DenseTile<T, NCT, V> &tl)
 {
     constexpr uint32_t n = NCT;
     // L_0 and R_{N-1} are never used (pcg.cuh:105-106); lanes without a row hold zeros
     const bool keep = dc.live && !(BLK == 0 && dc.k == 0) && !(BLK == 2 && dc.k == N - 1);
-    const dense_float2_alias *src = reinterpret_cast<const dense_float2_alias *>(buf + b9 * n * n + dc.rp * 2);
+    const dense_float2_alias *src = reinterpret_cast<const dense_float2_alias *>(buf + (size_t)b9 * n * n * sizeof(T) + dc.rp * 8);
 #pragma unroll
     for (uint32_t c = 0; c < n; ++c) {
-        const float2 v = src[c * n / 2];
-        tl.a[BLK * n + c][0] = keep ? v.x : 0.f;
-        tl.a[BLK * n + c][1] = keep ? v.y : 0.f;
+        const float2 v = src[c * n * sizeof(T) / 8];
+        if constexpr (sizeof(T) == 4) {
+            tl.a[BLK * n + c][0] = keep ? v.x : 0.f;
+            tl.a[BLK * n + c][1] = keep ? v.y : 0.f;
+        } else {
+            const unsigned long long b = ((unsigned long long)__builtin_bit_cast(uint32_t, v.y) << 32) | __builtin_bit_cast(uint32_t, v.x);
+            tl.a[BLK * n + c][0] = keep ? __builtin_bit_cast(double, b) : 0.0;
+        }
     }
 }
 
-
-template <int NCT, int V> constexpr size_t dense_stage_lds_bytes() { return (size_t)2 * DenseGeom<float, NCT, V>::WAVES * DenseStage<NCT, V>::BYTES; }
+template <typename T, int NCT, int V> constexpr size_t dense_stage_lds_bytes() { return (size_t)2 * DenseGeom<T, NCT, V>::WAVES * DenseStage<T, NCT, V>::BYTES; }
 
 // Both tiles of a workgroup's knots [k_lo, k_lo + cnt) through the staging buffers (`stage`: dense_stage_lds_bytes of LDS, 16-byte
 // aligned; matrices 16-byte aligned): six stages (S: L D R, Pinv: L D R; three when P == nullptr), two in flight, alternating
 // buffers.  `between` is called once, behind the first two stage issues: loads requested there (vectors) are younger than
 // two stages, which makes the first wait stricter than it has to be, never laxer.  tP is defined on every path (zeros
 // without a preconditioner): a conditionally loaded tile is carried around the caller's problem loop by hipcc, all of it.
-template <int NCT, int V, typename Between>
-__device__ __forceinline__ void dense_staged_load(const float *S, const float *P, uint32_t N, const DenseCtx<float, NCT, V> &dc,
-                                                  uint32_t wave, uint32_t lane, uint32_t k_lo, uint32_t cnt, float *stage,
-                                                  DenseTile<float, NCT, V> &tS, DenseTile<float, NCT, V> &tP, Between between)
+// P_TAIL (0 or n): the R block of Pinv is not picked into tP but left in LDS for dense_mv's TAIL form -- in the wave's OWN
+// first staging buffer (the last stage arrives in the second one, and a wave's LDS operations execute in order), one
+// 8-byte element per lane and column, lane-contiguous: tail[c * 64 + lane].  The wave must not stage anything else before
+// its solve is over.
+template <typename T, int NCT, int V, int P_TAIL = 0, typename Between>
+__device__ __forceinline__ void dense_staged_load(const T *S, const T *P, uint32_t N, const DenseCtx<T, NCT, V> &dc,
+                                                  uint32_t wave, uint32_t lane, uint32_t k_lo, uint32_t cnt, unsigned char *stage,
+                                                  DenseTile<T, NCT, V> &tS, DenseTile<T, NCT, V> &tP, Between between)
 {
-    using Dg = DenseGeom<float, NCT, V>;
+    static_assert(P_TAIL == 0 || (P_TAIL == NCT && (size_t)NCT * 64 * 8 <= DenseStage<T, NCT, V>::BYTES), "the whole R block, inside one staging buffer");
+    using Dg = DenseGeom<T, NCT, V>;
     constexpr uint32_t n = NCT;
     // this wave's knots [kw, kw + nk)
     const uint32_t kw = k_lo + wave * Dg::BPW;
     const uint32_t nk = wave * Dg::BPW < cnt ? (cnt - wave * Dg::BPW < Dg::BPW ? cnt - wave * Dg::BPW : Dg::BPW) : 0u;
     const uint32_t kbase = kw < N ? kw : N - 1;
-    float *buf0 = stage + wave * DenseStage<NCT, V>::FLOATS;
-    float *buf1 = buf0 + Dg::WAVES * DenseStage<NCT, V>::FLOATS;
+    unsigned char *buf0 = stage + wave * DenseStage<T, NCT, V>::BYTES;
+    unsigned char *buf1 = buf0 + Dg::WAVES * DenseStage<T, NCT, V>::BYTES;
     const uint32_t lds0 = (uint32_t)(uintptr_t)buf0, lds1 = (uint32_t)(uintptr_t)buf1;
-    const float *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
+    const T *Sw = S + (size_t)kbase * 3 * n * n, *Pw = (P ? P : S) + (size_t)kbase * 3 * n * n;
     const uint32_t b9 = dc.live ? lane / Dg::LPB : 0u;
-    dense_stage_issue<NCT, V>(Sw, lane, nk, lds0);
-    dense_stage_issue<NCT, V>(Sw + n * n, lane, nk, lds1);
+    dense_stage_issue<T, NCT, V>(Sw, lane, nk, lds0);
+    dense_stage_issue<T, NCT, V>(Sw + n * n, lane, nk, lds1);
     between();
-    dense_stage_wait<NCT, V, 1>();
-    dense_stage_pick<NCT, V, 0>(buf0, dc, b9, N, tS);
-    dense_stage_issue<NCT, V>(Sw + 2 * n * n, lane, nk, lds0);
-    dense_stage_wait<NCT, V, 1>();
-    dense_stage_pick<NCT, V, 1>(buf1, dc, b9, N, tS);
-    if (P) dense_stage_issue<NCT, V>(Pw, lane, nk, lds1);
-    if (P) dense_stage_wait<NCT, V, 1>(); else dense_stage_wait<NCT, V, 0>();
-    dense_stage_pick<NCT, V, 2>(buf0, dc, b9, N, tS);
+    dense_stage_wait<T, NCT, V, 1>();
+    dense_stage_pick<T, NCT, V, 0>(buf0, dc, b9, N, tS);
+    dense_stage_issue<T, NCT, V>(Sw + 2 * n * n, lane, nk, lds0);
+    dense_stage_wait<T, NCT, V, 1>();
+    dense_stage_pick<T, NCT, V, 1>(buf1, dc, b9, N, tS);
+    if (P) dense_stage_issue<T, NCT, V>(Pw, lane, nk, lds1);
+    if (P) dense_stage_wait<T, NCT, V, 1>(); else dense_stage_wait<T, NCT, V, 0>();
+    dense_stage_pick<T, NCT, V, 2>(buf0, dc, b9, N, tS);
     if (P) {
-        dense_stage_issue<NCT, V>(Pw + n * n, lane, nk, lds0);
-        dense_stage_wait<NCT, V, 1>();
-        dense_stage_pick<NCT, V, 0>(buf1, dc, b9, N, tP);
-        dense_stage_issue<NCT, V>(Pw + 2 * n * n, lane, nk, lds1);
-        dense_stage_wait<NCT, V, 1>();
-        dense_stage_pick<NCT, V, 1>(buf0, dc, b9, N, tP);
-        dense_stage_wait<NCT, V, 0>();
-        dense_stage_pick<NCT, V, 2>(buf1, dc, b9, N, tP);
+        dense_stage_issue<T, NCT, V>(Pw + n * n, lane, nk, lds0);
+        dense_stage_wait<T, NCT, V, 1>();
+        dense_stage_pick<T, NCT, V, 0>(buf1, dc, b9, N, tP);
+        dense_stage_issue<T, NCT, V>(Pw + 2 * n * n, lane, nk, lds1);
+        dense_stage_wait<T, NCT, V, 1>();
+        dense_stage_pick<T, NCT, V, 1>(buf0, dc, b9, N, tP);
+        dense_stage_wait<T, NCT, V, 0>();
+        if constexpr (P_TAIL == 0) {
+            dense_stage_pick<T, NCT, V, 2>(buf1, dc, b9, N, tP);
+        } else {
+            const bool keep = dc.live && dc.k != N - 1;   // R_{N-1} is never used; lanes without a row hold zeros
+            const dense_float2_alias *src = reinterpret_cast<const dense_float2_alias *>(buf1 + (size_t)b9 * n * n * sizeof(T) + dc.rp * 8);
+            dense_float2_alias *tail = reinterpret_cast<dense_float2_alias *>(buf0) + lane;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (uint32_t c = 0; c < n; ++c) {
+                const float2 v = src[c * n * sizeof(T) / 8];
+                tail[c * 64] = keep ? v : make_float2(0.f, 0.f);
+            }
+            asm volatile("" ::: "memory");
+        }
     } else {
 #pragma unroll
-        for (uint32_t cc = 0; cc < Dg::COLS; ++cc) tP.a[cc][0] = tP.a[cc][1] = 0.f;
+        for (uint32_t cc = 0; cc < Dg::COLS; ++cc)
+#pragma unroll
+            for (int j = 0; j < V; ++j) tP.a[cc][j] = T(0);
     }
 }
 

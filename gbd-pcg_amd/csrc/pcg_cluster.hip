@@ -57,58 +57,101 @@ constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on 
 
 // Workspace: [256-byte block: stamps of the diagnostic build, words 30 / 31 = finish counter / launch number |
 // per cluster two words: members that have left, and 2^32 - 1 - (first problem a member gave up on) maximised over the
-// members (0: none) | slots[2 parities][grid blocks]].  One slot = three 128-byte lines:
-//   +0    the 8 wave partials (8 granules)
-//   +128  the first own knot of the product vector, for the left neighbour  (n granules, two per 16-byte store)
-//   +256  the last own knot, for the right neighbour
-constexpr uint32_t kClLeftOff = 256, kClCtrlBytes = 256 + 256 * 16, kClSlotBytes = 384, kClFirstOff = 128, kClLastOff = 256;
+// members (0: none) | slots[2 parities][grid blocks]].  One slot:
+//   +0    the 8 wave partials (fp32: 8 granules of 8 bytes; fp64: 8 pairs of granules, 128 bytes)
+//   +128  the first own knot of the product vector, for the left neighbour: one 16-byte store {w0, tag, w1, tag} per lane of
+//         the knot (the lane's 8 bytes of payload: two fp32 rows, one fp64 row, or one fp32 row), up to 16 lanes
+//   +384  the last own knot, for the right neighbour
+constexpr uint32_t kClLeftOff = 256, kClCtrlBytes = 256 + 256 * 16, kClSlotBytes = 640, kClFirstOff = 128, kClLastOff = 384;
 constexpr uint32_t kClMaxH = 4;
 constexpr uint32_t kClEpochBits = 20, kClLaunchMod = 4095;   // tag = ((launch mod 4095) + 1) << 20 | epoch
 
-__device__ __forceinline__ uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
 
-// Lane roles of the polling wave in one gather: lanes [0, 4H) fetch two wave partials each (member L / 4, waves
-// 2 (L % 4), +1), lanes [32, 39) the left neighbour's last knot, lanes [40, 47) the right neighbour's first knot.
-constexpr uint32_t kClLeftLane = 32, kClRightLane = 40;
+// Lane roles of the polling wave in one gather: lanes [0, PPM H) fetch 16 bytes of wave partials each (fp32: PPM = 4 lanes per
+// member, two partials per lane; fp64: PPM = 8, one), lanes [32, 32 + LPB) the left neighbour's last knot, lanes
+// [48, 48 + LPB) the right neighbour's first knot (LPB = lanes per knot <= 16).
+constexpr uint32_t kClLeftLane = 32, kClRightLane = 48;
+
+// A lane's payload in a boundary store: its V rows as two 32-bit words.
+template <typename T, int V> __device__ __forceinline__ void cl_pack(const T (&v)[V], uint32_t &w0, uint32_t &w1)
+{
+    if constexpr (sizeof(T) == 8) {
+        const u64 b = __builtin_bit_cast(u64, v[0]);
+        w0 = (uint32_t)b;
+        w1 = (uint32_t)(b >> 32);
+    } else {
+        w0 = __builtin_bit_cast(uint32_t, v[0]);
+        w1 = V > 1 ? __builtin_bit_cast(uint32_t, v[V - 1]) : 0u;
+    }
+}
+template <typename T, int V> __device__ __forceinline__ void cl_unpack(uint32_t w0, uint32_t w1, T (&v)[V])
+{
+    if constexpr (sizeof(T) == 8) {
+        v[0] = __builtin_bit_cast(double, ((u64)w1 << 32) | w0);
+    } else {
+        v[0] = __builtin_bit_cast(float, w0);
+        if constexpr (V > 1) v[1] = __builtin_bit_cast(float, w1);
+    }
+}
+// The wave partials a partial lane fetched (16 bytes): two fp32 partials, or one fp64 partial.
+template <typename T> __device__ __forceinline__ T cl_partials(uint32_t w0, uint32_t w1)
+{
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(double, ((u64)w1 << 32) | w0);
+    else return __builtin_bit_cast(float, w0) + __builtin_bit_cast(float, w1);
+}
 
 #ifndef GBDPCG_CL_PTAIL
 #define GBDPCG_CL_PTAIL 0   // columns of a lane's Pinv block-row kept in LDS instead of registers (0, 2, 4, ...): not needed since the kernel compiles without scratch; kept for A/B builds
 #endif
-template <int NCT> struct ClusterTail { static constexpr int COLS = NCT == 16 ? 16 : GBDPCG_CL_PTAIL; };
+template <typename T, int NCT> struct ClusterTail {
+    static constexpr int COLS = (sizeof(T) == 4 && NCT == 16) ? 16 : (sizeof(T) == 8 && NCT == 14) ? 14 : (NCT % 2 == 0 ? GBDPCG_CL_PTAIL : 0);
+};
+// bytes between the tails of two waves in dynamic LDS
+template <typename T, int NCT, int V, bool STAGED> struct ClusterTailBytes {
+    static constexpr size_t PER_WAVE = STAGED ? (size_t)DenseStage<T, NCT, V>::BYTES : (size_t)ClusterTail<T, NCT>::COLS * 64 * 8;
+};
 #ifndef GBDPCG_CL_CHAINS
 #define GBDPCG_CL_CHAINS 3   // accumulator chains of a block-row product (bt_dense.hpp, dense_mv); 1 for A/B builds
 #endif
 
 }  // namespace
 
-template <int NCT, int V, bool STAGED>
-__global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsigned char *ws, uint32_t H, uint32_t C,
+template <typename T, int NCT, int V, bool STAGED>
+__global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
                                                           uint32_t clusters, uint32_t spin_limit, uint32_t drop_block, bool no_plain)
 {
 #ifndef GBDPCG_TEST_HOOKS
     drop_block = 0xffffffffu;   // the hook that silences one workgroup exists in variants/libgbdpcg_hooks.so only
 #endif
     constexpr uint32_t epoch_bits = kClEpochBits;
-    using Dg = DenseGeom<float, NCT, V>;
-    // lane roles below: n / 2 lanes x 2 rows per knot (a knot's boundary values are one 128-byte line of 16-byte granule pairs:
-    // n / 2 <= 8), 8 waves (lanes 4H..: partials of the 8 H waves, two per lane)
-    static_assert(V == 2 && NCT % 2 == 0 && NCT <= 16 && Dg::WAVES == 8, "lane roles below are written for n / 2 lanes x 2 rows per knot");
-    constexpr uint32_t n = NCT, THREADS = Dg::WAVES * 64, WINF = align16<float>((Dg::MAX_KNOTS + 2) * n);
-    __shared__ __attribute__((aligned(16))) float xa[WINF];   // window of p (lambda in the prologue): halo knot, own knots, halo knot
-    __shared__ __attribute__((aligned(16))) float xb[WINF];   // window of r
-    __shared__ float bc[4];       // [0] alpha / eta' of the phase just gathered, [1] beta
+    using Dg = DenseGeom<T, NCT, V>;
+    // lane roles below: LPB = n / V lanes per knot (<= 16: a knot's boundary values are LPB 16-byte stores), a lane's rows are 8
+    // bytes of payload at most, 8 waves (partial lanes: 16 bytes of the 8 H wave partials each)
+    static_assert(V * sizeof(T) <= 8 && NCT % V == 0 && Dg::LPB <= 16 && Dg::WAVES == 8, "lane roles of the hand-off");
+    constexpr uint32_t n = NCT, LPB = Dg::LPB, THREADS = Dg::WAVES * 64, WINF = align16<T>((Dg::MAX_KNOTS + 2) * n);
+    constexpr uint32_t PPM = sizeof(T) == 4 ? 4u : 8u;   // partial lanes per member
+    constexpr int CHAINS = NCT % 2 == 0 ? GBDPCG_CL_CHAINS : 1;   // (one chain per block needs whole operand pairs per block)
+    __shared__ __attribute__((aligned(16))) T xa[WINF];   // window of p (lambda in the prologue): halo knot, own knots, halo knot
+    __shared__ __attribute__((aligned(16))) T xb[WINF];   // window of r
+    __shared__ T bc[4];           // [0] alpha / eta' of the phase just gathered, [1] beta
     __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out; [2], [3] the rescue's bookkeeping
-    __shared__ float rescue_red[2 * Dg::WAVES];
+    __shared__ T rescue_red[2 * Dg::WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: dense_stage_lds_bytes (bt_dense.hpp)
-    // The last PTAIL columns of this lane's block-row of Pinv (two rows each) live in LDS instead of registers (dense_mv, TAIL):
-    // at n = 16 the whole R block of Pinv -- 2 x 96 matrix registers per lane do not fit next to the working set, 96 + 64 do.
+    // The last PTAIL columns of this lane's block-row of Pinv (its V rows each) live in LDS instead of registers (dense_mv, TAIL):
+    // at n = 16 the whole R block of Pinv -- 2 x 96 matrix registers per lane do not fit next to the working set, 96 + 64 do;
+    // likewise in fp64 at n = 14 (2 x 84 registers of matrix data next to a working set of twice the width: 84 + 56).
     // They take the place of the staging buffers once every wave's tiles are in (cluster_lds_bytes).
-    constexpr int PTAIL = ClusterTail<NCT>::COLS;
-    float2 *ptail = reinterpret_cast<float2 *>(stage_raw);
+    constexpr int PTAIL = ClusterTail<T, NCT>::COLS;
+    // Every wave keeps its own: in its first staging buffer when the tiles come in staged (bt_dense.hpp, dense_staged_load: the
+    // block goes from the second buffer straight there, never through registers), else in PTAIL x 64 elements of its own.
+    using TV = typename DenseTailElem<T, V>::type;
+    static_assert(PTAIL == 0 || sizeof(TV) == 8, "a lane's rows of a tail column are 8 bytes");
 
     const uint32_t N = a.N, len = n * N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TV *ptail = reinterpret_cast<TV *>(stage_raw + (size_t)wave * ClusterTailBytes<T, NCT, V, STAGED>::PER_WAVE);
+    const TV *pt_lane = ptail + lane;
     const uint32_t grid = gridDim.x, blk = blockIdx.x;
     // cluster c, member h.  Members sit 8 blocks apart where the cluster count allows it: blocks b and b + 8 share an XCD
     // under round-robin dispatch (a hand-off inside one L2 is ~20 % shorter).  Speed only: nothing depends on placement.
@@ -120,14 +163,14 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     const uint32_t k_lo = h * C, cnt = k_lo < N ? (N - k_lo < C ? N - k_lo : C) : 0u;   // host: cnt >= 1 for every member
     const bool has_left = h > 0, has_right = h + 1 < H;
 
-    const DenseCtx<float, NCT, V> dc(wave, lane, cnt, k_lo);
-    // first of this lane's rows, counted from knot k_lo: (wave * 9 + lane / 7) * 14 + (lane % 7) * 2 = wave * 126 + 2 * lane
-    const uint32_t row0 = dc.live ? wave * (Dg::BPW * n) + 2 * lane : 0u;
+    const DenseCtx<T, NCT, V> dc(wave, lane, cnt, k_lo);
+    // first of this lane's rows, counted from knot k_lo: (wave BPW + lane / LPB) n + (lane % LPB) V = wave BPW n + V lane (n = V LPB)
+    const uint32_t row0 = dc.live ? wave * (Dg::BPW * n) + V * lane : 0u;
     // the same index inside a window, from an opaque copy of the lane number (see GBDPCG_CL_HANDOFF: not worth a register)
     auto own_idx = [&]() {
         uint32_t lo = lane;
         asm volatile("" : "+v"(lo));
-        return n + wave * (Dg::BPW * n) + 2 * lo;
+        return n + wave * (Dg::BPW * n) + V * lo;
     };
     const uint32_t wl = (cnt - 1) / Dg::BPW, lb = (cnt - 1) - wl * Dg::BPW;   // the last knot: wave wl, lanes [7 lb, 7 lb + 7)
     const uint32_t POLL = wl == 7 ? 6u : 7u;                          // the polling wave: never wave 0, never wave wl
@@ -152,47 +195,58 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
     // What a lane does follows from its lane number alone; it is recomputed here from an opaque copy of it, every time:
     // kept in registers across the products (168 of 256 VGPRs hold matrix data) these few values were spilled, and each
     // reload from scratch sat, with its s_waitcnt vmcnt(0), in front of the very stores the neighbour is waiting for.
-#define GBDPCG_CL_HANDOFF(EPOCH, PART, V0, V1, HWIN, TOTAL, G0, G1, H0, H1, HIDX, OK)                               \
+#define GBDPCG_CL_HANDOFF(EPOCH, PART, VALS, HWIN, TOTAL, GV, HV, HIDX, OK, GOTX, GOTZ)                               \
     {                                                                                                                \
         const uint32_t tag = nonce | (EPOCH), par_off = ((EPOCH) & 1u) * par_stride;                                 \
         uint32_t lo = lane;                                                                                          \
         asm volatile("" : "+v"(lo));                                                                                 \
         if (blk != drop_block) {                                                                                     \
-            const cl_u32x2 x = {fbits(PART), tag};                                                                   \
-            const cl_u32x4 bx = {fbits(V0), tag, fbits(V1), tag};                                                    \
-            const int o_part = (int)(par_off + my_slot + wave * 8), o_first = (int)(par_off + my_slot + kClFirstOff + lo * 16), \
-                      o_last = (int)(par_off + my_slot + kClLastOff + (lo - lb * (n / 2)) * 16);                     \
-            const bool p_first = wave == 0 && has_left && lo < n / 2, p_last = wave == wl && has_right && lo - lb * (n / 2) < n / 2; \
+            uint32_t w0, w1, q0, q1;                                                                                 \
+            cl_pack<T, V>(VALS, w0, w1);                                                                             \
+            const T part_[1] = {PART};                                                                               \
+            cl_pack<T, 1>(part_, q0, q1);                                                                            \
+            const cl_u32x2 x2 = {q0, tag};                                                                           \
+            const cl_u32x4 x4 = {q0, tag, q1, tag};                                                                  \
+            const cl_u32x4 bx = {w0, tag, w1, tag};                                                                  \
+            const int o_part = (int)(par_off + my_slot + wave * (sizeof(T) == 4 ? 8u : 16u)),                        \
+                      o_first = (int)(par_off + my_slot + kClFirstOff + lo * 16),                                    \
+                      o_last = (int)(par_off + my_slot + kClLastOff + (lo - lb * LPB) * 16);                         \
+            const bool p_first = wave == 0 && has_left && lo < LPB, p_last = wave == wl && has_right && lo - lb * LPB < LPB; \
             if (same_xcd) {   /* plain: the line stays in this XCD's L2, where every member of the cluster polls */   \
-                if (lo == 0) __builtin_amdgcn_raw_buffer_store_b64(x, region, o_part, 0, 0);                         \
+                if (lo == 0) {                                                                                       \
+                    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b64(x2, region, o_part, 0, 0);   \
+                    else __builtin_amdgcn_raw_buffer_store_b128(x4, region, o_part, 0, 0);                           \
+                }                                                                                                    \
                 if (p_first) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_first, 0, 0);                      \
                 if (p_last) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_last, 0, 0);                        \
             } else {          /* sc1: write-through, seen from any XCD */                                            \
-                if (lo == 0) __builtin_amdgcn_raw_buffer_store_b64(x, region, o_part, 0, kClSc1);                    \
+                if (lo == 0) {                                                                                       \
+                    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b64(x2, region, o_part, 0, kClSc1); \
+                    else __builtin_amdgcn_raw_buffer_store_b128(x4, region, o_part, 0, kClSc1);                      \
+                }                                                                                                    \
                 if (p_first) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_first, 0, kClSc1);                 \
                 if (p_last) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_last, 0, kClSc1);                   \
             }                                                                                                        \
         }                                                                                                            \
-        if (wave == POLL) {                                                                    \
+        if (wave == POLL) {                                                                                          \
             uint32_t poll_off = 0;                                                                                   \
             bool have = true;                                                                                        \
             HIDX = 0xffffffffu;                                                                                      \
-            if (lo < 4 * H) {                                                                                        \
-                poll_off = (blk0 + (lo >> 2) * bstride) * kClSlotBytes + (lo & 3u) * 16;                             \
+            if (lo < PPM * H) {                                                                                      \
+                poll_off = (blk0 + (lo / PPM) * bstride) * kClSlotBytes + (lo % PPM) * 16;                           \
                 have = false;                                                                                        \
-            } else if (lo - kClLeftLane < n / 2 && has_left) {                                                       \
+            } else if (lo - kClLeftLane < LPB && has_left) {                                                         \
                 poll_off = (blk - bstride) * kClSlotBytes + kClLastOff + (lo - kClLeftLane) * 16;                    \
-                HIDX = (lo - kClLeftLane) * 2;                                                                       \
+                HIDX = (lo - kClLeftLane) * V;                                                                       \
                 have = false;                                                                                        \
-            } else if (lo - kClRightLane < n / 2 && has_right) {                                                     \
+            } else if (lo - kClRightLane < LPB && has_right) {                                                       \
                 poll_off = (blk + bstride) * kClSlotBytes + kClFirstOff + (lo - kClRightLane) * 16;                  \
-                HIDX = (cnt + 1) * n + (lo - kClRightLane) * 2;                                                      \
+                HIDX = (cnt + 1) * n + (lo - kClRightLane) * V;                                                      \
                 have = false;                                                                                        \
             }                                                                                                        \
             /* the halo entries this lane is going to update: read now, under the wait */                           \
             if (HIDX != 0xffffffffu) {                                                                               \
-                H0 = (HWIN)[HIDX];                                                                                   \
-                H1 = (HWIN)[HIDX + 1];                                                                               \
+                _Pragma("unroll") for (int j_ = 0; j_ < V; ++j_) HV[j_] = (HWIN)[HIDX + j_];                         \
             }                                                                                                        \
             cl_u32x4 got = {0u, 0u, 0u, 0u};                                                                         \
             OK = true;                                                                                               \
@@ -211,10 +265,10 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }                                                                                                        \
             /* by value: __builtin_bit_cast applied to the element expression got.z itself reads element 0 (hipcc,   \
                ROCm 7.2) */                                                                                          \
-            const uint32_t gx = got.x, gz = got.z;                                                                   \
-            G0 = __builtin_bit_cast(float, gx);                                                                      \
-            G1 = __builtin_bit_cast(float, gz);                                                                      \
-            TOTAL = wave_sum(lo < 4 * H ? G0 + G1 : 0.f);                                                            \
+            GOTX = got.x;                                                                                            \
+            GOTZ = got.z;                                                                                            \
+            cl_unpack<T, V>(GOTX, GOTZ, GV);                                                                         \
+            TOTAL = wave_sum(lo < PPM * H ? cl_partials<T>(GOTX, GOTZ) : T(0));                                      \
         }                                                                                                            \
     }
 
@@ -271,10 +325,13 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #pragma unroll
         for (uint32_t par = 0; par < 2; ++par) {
             const uint32_t o = par * par_stride + my_slot;
-            if (lo == 0) __builtin_amdgcn_raw_buffer_store_b64(z2, region, (int)(o + wave * 8), 0, kClSc1);
-            if (wave == 0 && has_left && lo < n / 2) __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + kClFirstOff + lo * 16), 0, kClSc1);
-            if (wave == wl && has_right && lo - lb * (n / 2) < n / 2)
-                __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + kClLastOff + (lo - lb * (n / 2)) * 16), 0, kClSc1);
+            if (lo == 0) {
+                if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b64(z2, region, (int)(o + wave * 8), 0, kClSc1);
+                else __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + wave * 16), 0, kClSc1);
+            }
+            if (wave == 0 && has_left && lo < LPB) __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + kClFirstOff + lo * 16), 0, kClSc1);
+            if (wave == wl && has_right && lo - lb * LPB < LPB)
+                __builtin_amdgcn_raw_buffer_store_b128(z4, region, (int)(o + kClLastOff + (lo - lb * LPB) * 16), 0, kClSc1);
         }
     }
     if (any) for (uint32_t prob = c; prob < a.batch; prob += clusters) {
@@ -287,20 +344,26 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             continue;
         }
         GBDPCG_CL_STAMP_RT(14, 0, ordinal == 3)
-        float total = 0.f, g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f, part;
-        uint32_t hidx = 0xffffffffu;
+        T total = T(0), gv[V], hv[V], part;
+#pragma unroll
+        for (int j = 0; j < V; ++j) gv[j] = hv[j] = T(0);
+        uint32_t hidx = 0xffffffffu, gotx = 0u, gotz = 0u;
         bool ok = true;
         if (!greeted) {
             // HELLO (epoch 1): where does everybody run?  The payload of every partial granule is the sender's XCD id.
             greeted = true;
-            const float my_id = __builtin_bit_cast(float, xcc_id);
+            T my_id, zeros[V];   // a partial whose words both read xcc_id
+#pragma unroll
+            for (int j = 0; j < V; ++j) zeros[j] = T(0);
+            if constexpr (sizeof(T) == 4) my_id = __builtin_bit_cast(float, xcc_id);
+            else my_id = __builtin_bit_cast(double, ((u64)xcc_id << 32) | xcc_id);
             if (tid == 0) bci[0] = 0u;
             wg_barrier();
-            GBDPCG_CL_HANDOFF(1u, my_id, 0.f, 0.f, xa, total, g0, g1, h0, h1, hidx, ok)
+            GBDPCG_CL_HANDOFF(1u, my_id, zeros, xa, total, gv, hv, hidx, ok, gotx, gotz)
             if (wave == POLL) {
                 uint32_t lo = lane;
                 asm volatile("" : "+v"(lo));
-                const bool mine = lo >= 4 * H || (fbits(g0) == xcc_id && fbits(g1) == xcc_id);
+                const bool mine = lo >= PPM * H || (gotx == xcc_id && gotz == xcc_id);
                 const bool all_here = __all(mine);
                 if (lane == 0) {
                     bci[0] = ok ? 0u : 2u;
@@ -321,22 +384,22 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
         }
         const uint32_t e0 = 1u + ordinal * epochs_per_problem;   // epochs e0 + 1 .. e0 + 2 max_iter + 2 belong to this problem
-        const float *S = a.S + prob * mstride;
-        const float *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;   // nullptr: identity preconditioner
+        const T *S = a.S + prob * mstride;
+        const T *P = a.Pinv ? a.Pinv + prob * mstride : nullptr;   // nullptr: identity preconditioner
         const size_t voff = (size_t)prob * len;
 
         // lambda and gamma of this lane's rows and the two halo knots of lambda (straight from the input vector: no member
         // writes lambda before every member has passed its first hand-off) are requested next to the first tile stages, so
         // that their round trips run under the 300 KB of tile loads instead of in front of the first product
-        float lamv[V], gamv[V], halo_lam = 0.f;
+        T lamv[V], gamv[V], halo_lam = T(0);
         auto request_vectors = [&]() {
             uint32_t lo = lane;
             asm volatile("" : "+v"(lo));   // addresses from the lane number, not from registers held since the kernel started
-            const size_t g0 = voff + (size_t)k_lo * n + wave * (Dg::BPW * n) + 2 * lo;
+            const size_t g0 = voff + (size_t)k_lo * n + wave * (Dg::BPW * n) + V * lo;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                lamv[j] = dc.live ? a.lambda[g0 + j] : 0.f;
-                gamv[j] = dc.live ? a.gamma[g0 + j] : 0.f;
+                lamv[j] = dc.live ? a.lambda[g0 + j] : T(0);
+                gamv[j] = dc.live ? a.gamma[g0 + j] : T(0);
             }
             const uint32_t t = wave * 64 + lo;
             if (t < 2 * n) {   // threads [0, n): the knot before the own ones, [n, 2n): the knot after them
@@ -345,26 +408,35 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             }
         };
 
-        DenseTile<float, NCT, V> tS, tP;
+        DenseTile<T, NCT, V> tS, tP;
         if constexpr (STAGED) {
             GBDPCG_CL_STAMP(12, 0, ordinal == 0)
-            dense_staged_load<NCT, V>(S, P, N, dc, wave, lane, k_lo, cnt, reinterpret_cast<float *>(stage_raw), tS, tP,
+            dense_staged_load<T, NCT, V, PTAIL>(S, P, N, dc, wave, lane, k_lo, cnt, stage_raw, tS, tP,
                                       request_vectors);   // the vectors are requested behind the first two tile stages
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last picks are in registers before anything else happens
             GBDPCG_CL_STAMP(13, 0, ordinal == 0)
             GBDPCG_CL_STAMP_RT(15, 0, ordinal == 3)
         } else {
             request_vectors();
-            dense_load<float, NCT, V>(S, N, dc, tS);
+            dense_load<T, NCT, V>(S, N, dc, tS);
             if (P) {
-                dense_load<float, NCT, V>(P, N, dc, tP);
+                dense_load<T, NCT, V>(P, N, dc, tP);
+                if constexpr (PTAIL > 0) {   // (direct loads: the tail goes through the registers, once per problem)
+#pragma unroll
+                    for (int t = 0; t < PTAIL; ++t) {
+                        if constexpr (V == 2) ptail[t * 64 + lane] = TV{tP.a[Dg::COLS - PTAIL + t][0], tP.a[Dg::COLS - PTAIL + t][1]};
+                        else ptail[t * 64 + lane] = tP.a[Dg::COLS - PTAIL + t][0];
+                    }
+                }
             } else {
 #pragma unroll
-                for (uint32_t cc = 0; cc < Dg::COLS; ++cc) tP.a[cc][0] = tP.a[cc][1] = 0.f;
+                for (uint32_t cc = 0; cc < Dg::COLS; ++cc)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) tP.a[cc][j] = T(0);
             }
         }
 
-        float rv[V], pv[V], yv[V];
+        T rv[V], pv[V], yv[V];
         // windows: lambda on the own knots and the halos, zeros behind them (rows past the own knots, halos at the ends
         // of the problem); every entry has exactly one writer
         if (dc.live) {
@@ -374,44 +446,42 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         if (tid < 2 * n) {
             const uint32_t i = tid < n ? tid : (cnt + 1) * n + (tid - n);
             xa[i] = halo_lam;
-            xb[i] = 0.f;
+            xb[i] = T(0);
         }
         {
             uint32_t t = tid;
             asm volatile("" : "+v"(t));
-            for (uint32_t i = (cnt + 2) * n + t; i < WINF; i += THREADS) xa[i] = xb[i] = 0.f;
+            for (uint32_t i = (cnt + 2) * n + t; i < WINF; i += THREADS) xa[i] = xb[i] = T(0);
         }
         if (tid == 0) bci[0] = 0u;
         wg_barrier();
-        if (PTAIL > 0 && P) {   // (behind the barrier: every wave is done with its staging buffers, which this overwrites)
-#pragma unroll
-            for (int t = 0; t < PTAIL; ++t)
-                ptail[t * THREADS + tid] = make_float2(tP.a[Dg::COLS - PTAIL + t][0], tP.a[Dg::COLS - PTAIL + t][1]);
-        }
         GBDPCG_CL_STAMP_RT(16, 0, ordinal == 3)
 
         // r = gamma - S lambda                                            (pcg.cuh:118-126); the boundary knots of r travel
-        dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tS, xa, dc, yv);
+        dense_mv<T, NCT, V, CHAINS>(tS, xa, dc, yv);
 #pragma unroll
-        for (int j = 0; j < V; ++j) rv[j] = dc.live ? gamv[j] - yv[j] : 0.f;
+        for (int j = 0; j < V; ++j) rv[j] = dc.live ? gamv[j] - yv[j] : T(0);
         if (dc.live) {
 #pragma unroll
             for (int j = 0; j < V; ++j) xb[n + row0 + j] = rv[j];
         }
-        GBDPCG_CL_HANDOFF(e0 + 1u, 0.f, rv[0], rv[1], xb, total, g0, g1, h0, h1, hidx, ok)
+        GBDPCG_CL_HANDOFF(e0 + 1u, T(0), rv, xb, total, gv, hv, hidx, ok, gotx, gotz)
         if (wave == POLL) {
             if (!ok && lane == 0) bci[0] = 2u;
-            if (ok && hidx != 0xffffffffu) { xb[hidx] = g0; xb[hidx + 1] = g1; }
+            if (ok && hidx != 0xffffffffu) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) xb[hidx + j] = gv[j];
+            }
         }
         wg_barrier();
         bool failed = bci[0] == 2u;
         GBDPCG_CL_STAMP_RT(17, 0, ordinal == 3)
 
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
-        float eta = 0.f;
+        T eta = T(0);
         if (!failed) {
-            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
-            part = 0.f;
+            if (P) dense_mv<T, NCT, V, CHAINS, PTAIL>(tP, xb, dc, yv, pt_lane, 64);
+            part = T(0);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 pv[j] = P ? yv[j] : rv[j];
@@ -422,13 +492,16 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #pragma unroll
                 for (int j = 0; j < V; ++j) xa[n + row0 + j] = pv[j];
             }
-            GBDPCG_CL_HANDOFF(e0 + 2u, part, pv[0], pv[1], xa, total, g0, g1, h0, h1, hidx, ok)
+            GBDPCG_CL_HANDOFF(e0 + 2u, part, pv, xa, total, gv, hv, hidx, ok, gotx, gotz)
             if (wave == POLL) {
                 if (lane == 0) {
                     if (!ok) bci[0] = 2u;
                     bc[0] = total;
                 }
-                if (ok && hidx != 0xffffffffu) { xa[hidx] = g0; xa[hidx + 1] = g1; }
+                if (ok && hidx != 0xffffffffu) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) xa[hidx + j] = gv[j];
+                }
             }
             wg_barrier();
             failed = bci[0] == 2u;
@@ -442,54 +515,58 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             // upsilon = S p ; alpha = eta / (p.upsilon)                   (pcg.cuh:156-169)
             GBDPCG_CL_STAMP(1, POLL, iter == 3 && ordinal == 0)
             GBDPCG_CL_STAMP(8, 0, iter == 3 && ordinal == 0)
-            dense_mv<float, NCT, V, GBDPCG_CL_CHAINS>(tS, xa, dc, yv);
-            part = 0.f;
+            dense_mv<T, NCT, V, CHAINS>(tS, xa, dc, yv);
+            part = T(0);
 #pragma unroll
             for (int j = 0; j < V; ++j) part = fma_t(pv[j], yv[j], part);
             part = wave_sum(part);
             GBDPCG_CL_STAMP(2, POLL, iter == 3 && ordinal == 0)
             GBDPCG_CL_STAMP(9, 0, iter == 3 && ordinal == 0)
-            GBDPCG_CL_HANDOFF(e0 + 3u + 2u * iter, part, yv[0], yv[1], xb, total, g0, g1, h0, h1, hidx, ok)
+            GBDPCG_CL_HANDOFF(e0 + 3u + 2u * iter, part, yv, xb, total, gv, hv, hidx, ok, gotx, gotz)
             GBDPCG_CL_STAMP(3, POLL, iter == 3 && ordinal == 0)
             GBDPCG_CL_STAMP(10, 0, iter == 3 && ordinal == 0)
             if (wave == POLL) {
-                const float al = eta / total;
+                const T al = eta / total;
                 if (lane == 0) {
                     if (!ok) bci[0] = 2u;
                     bc[0] = al;
                 }
                 // r -= alpha upsilon on the halo knots: the owner's fma on the owner's bits
                 if (ok && hidx != 0xffffffffu) {
-                    xb[hidx] = fma_t(-al, g0, h0);
-                    xb[hidx + 1] = fma_t(-al, g1, h1);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) xb[hidx + j] = fma_t(-al, gv[j], hv[j]);
                 }
             }
             wg_barrier();
             GBDPCG_CL_STAMP(4, POLL, iter == 3 && ordinal == 0)
             if (bci[0] == 2u) { failed = true; break; }
-            const float alpha = bc[0];
+            const T alpha = bc[0];
             // lambda += alpha p ; r -= alpha upsilon                      (pcg.cuh:172-176)
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 lamv[j] = fma_t(alpha, pv[j], lamv[j]);
                 rv[j] = fma_t(-alpha, yv[j], rv[j]);
             }
-            if (dc.live) *reinterpret_cast<float2 *>(xb + own_idx()) = make_float2(rv[0], rv[1]);
+            if (dc.live) {
+                const uint32_t oi = own_idx();
+#pragma unroll
+                for (int j = 0; j < V; ++j) xb[oi + j] = rv[j];
+            }
             wg_barrier();
             GBDPCG_CL_STAMP(5, POLL, iter == 3 && ordinal == 0)
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            if (P) dense_mv<float, NCT, V, GBDPCG_CL_CHAINS, PTAIL>(tP, xb, dc, yv, ptail + tid, THREADS);
-            part = 0.f;
+            if (P) dense_mv<T, NCT, V, CHAINS, PTAIL>(tP, xb, dc, yv, pt_lane, 64);
+            part = T(0);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 if (!P) yv[j] = rv[j];
                 part = fma_t(rv[j], yv[j], part);
             }
             part = wave_sum(part);
-            GBDPCG_CL_HANDOFF(e0 + 4u + 2u * iter, part, yv[0], yv[1], xa, total, g0, g1, h0, h1, hidx, ok)
+            GBDPCG_CL_HANDOFF(e0 + 4u + 2u * iter, part, yv, xa, total, gv, hv, hidx, ok, gotx, gotz)
             if (wave == POLL) {
-                const bool conv = fabsf(total) < a.tol;                   // pcg.cuh:195
-                const float be = total / eta;                             // pcg.cuh:199
+                const bool conv = fabs(total) < a.tol;                   // pcg.cuh:195
+                const T be = total / eta;                             // pcg.cuh:199
                 if (lane == 0) {
                     bci[0] = !ok ? 2u : (conv ? 1u : 0u);
                     bc[0] = total;
@@ -497,8 +574,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 }
                 // p = r~ + beta p on the halo knots                       (pcg.cuh:203-206)
                 if (ok && !conv && hidx != 0xffffffffu) {
-                    xa[hidx] = fma_t(be, h0, g0);
-                    xa[hidx + 1] = fma_t(be, h1, g1);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) xa[hidx + j] = fma_t(be, hv[j], gv[j]);
                 }
             }
             wg_barrier();
@@ -510,11 +587,15 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
                 break;
             }
             GBDPCG_CL_STAMP(6, POLL, iter == 3 && ordinal == 0)
-            const float beta = bc[1];
+            const T beta = bc[1];
             eta = bc[0];
 #pragma unroll
             for (int j = 0; j < V; ++j) pv[j] = fma_t(beta, pv[j], yv[j]);
-            if (dc.live) *reinterpret_cast<float2 *>(xa + own_idx()) = make_float2(pv[0], pv[1]);
+            if (dc.live) {
+                const uint32_t oi = own_idx();
+#pragma unroll
+                for (int j = 0; j < V; ++j) xa[oi + j] = pv[j];
+            }
             wg_barrier();
             GBDPCG_CL_STAMP(7, POLL, iter == 3 && ordinal == 0)
         }
@@ -526,7 +607,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
             // loop these were the kernel's last spills to scratch)
             uint32_t lo = lane;
             asm volatile("" : "+v"(lo));
-            const size_t g = voff + (size_t)k_lo * n + wave * (Dg::BPW * n) + 2 * lo;
+            const size_t g = voff + (size_t)k_lo * n + wave * (Dg::BPW * n) + V * lo;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 a.lambda[g + j] = lamv[j];
@@ -569,9 +650,9 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
         __syncthreads();
         const uint32_t from = bci[2];
         if (from != 0xffffffffu) {
-            float *vec = reinterpret_cast<float *>(a.rescue_vec) + (size_t)c * rescue_vec_elems<float>(n, N);
+            T *vec = reinterpret_cast<T *>(a.rescue_vec) + (size_t)c * rescue_vec_elems<T>(n, N);
             for (uint32_t prob = from; prob < a.batch; prob += clusters)
-                if (pcg_takes(a, prob)) stream_rescue<float, Dg::WAVES>(a, prob, vec, rescue_red);
+                if (pcg_takes(a, prob)) stream_rescue<T, Dg::WAVES>(a, prob, vec, rescue_red);
         }
     }
     // ---- the workgroup that finishes last gives the next launch its number ------------------------------------------------
@@ -593,21 +674,24 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<float> a, unsi
 #undef GBDPCG_CL_STAMP_RT
 }
 
-// The block sizes the kernel is built for (fp32, two rows per lane, n / 2 <= 8 lanes per knot; the staged tile loads want
-// n^2 % 4 == 0).  2 x 3n x 2 matrix registers per lane must leave room for the working set: at n = 16 (192) the R block of
-// Pinv stays in LDS (ClusterTail).
-#define GBDPCG_CLUSTER_N(X) X(8) X(10) X(12) X(14) X(16)
+// What the kernel is built for: X(element type, block size, rows per lane).  A lane's rows of one column are 8 bytes at most
+// (two fp32 rows, or one fp64 / fp32 row), n / V <= 16 lanes make a knot, and 2 x 3n x V x sizeof(T) / 4 matrix registers per
+// lane must leave room for the working set: at n = 16 (fp32, V = 2: 192) the R block of Pinv stays in LDS (ClusterTail).
+// fp64 at the BASELINE block size runs one row per lane: 14 lanes per knot, 32 knots per workgroup, four workgroups for N = 128.
+// stateSize 13 (odd: one fp32 row per lane, direct tile loads -- its blocks are not whole 16-byte pieces -- and one accumulator
+// chain per row).
+#define GBDPCG_CLUSTER_SHAPES(X) X(float, 8, 2) X(float, 10, 2) X(float, 12, 2) X(float, 13, 1) X(float, 14, 2) X(float, 16, 2) X(double, 14, 1)
 
-// fp32, general storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n/2))
-// knots -- 72 at n = 14, 80 at n = 12) up to kClMaxH times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
+// General storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n / V)) knots
+// -- 72 at n = 14 in fp32) up to kClMaxH times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
 template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
 {
     static const bool off = getenv("GBDPCG_NO_CLUSTER") != nullptr;
-    if (off || sizeof(T) != 4) return 0;
+    if (off) return 0;
     uint32_t per_wg = 0;
-#define GBDPCG_X(NN) \
-    if (n == NN) per_wg = DenseGeom<float, NN, 2>::MAX_KNOTS;
-    GBDPCG_CLUSTER_N(GBDPCG_X)
+#define GBDPCG_X(TT, NN, VV) \
+    if (sizeof(T) == sizeof(TT) && n == NN) per_wg = DenseGeom<TT, NN, VV>::MAX_KNOTS;
+    GBDPCG_CLUSTER_SHAPES(GBDPCG_X)
 #undef GBDPCG_X
     if (per_wg == 0 || N <= per_wg) return 0;   // not built for the block size / pcg_resident.hip has it in one workgroup
     const uint32_t H = (N + per_wg - 1) / per_wg;
@@ -620,54 +704,63 @@ size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (s
 // Device memory for the in-kernel rescue: one set of vectors per cluster, sized for the longest horizon the path takes.
 size_t cluster_rescue_bytes(const DeviceInfo &dev)
 {
-    size_t elems = 0;
-#define GBDPCG_X(NN)                                                                                       \
-    {                                                                                                      \
-        const size_t e = rescue_vec_elems<float>(NN, kClMaxH * DenseGeom<float, NN, 2>::MAX_KNOTS);        \
-        elems = e > elems ? e : elems;                                                                     \
+    size_t bytes = 0;
+#define GBDPCG_X(TT, NN, VV)                                                                                      \
+    {                                                                                                              \
+        const size_t e = rescue_vec_elems<TT>(NN, kClMaxH * DenseGeom<TT, NN, VV>::MAX_KNOTS) * sizeof(TT);       \
+        bytes = e > bytes ? e : bytes;                                                                             \
     }
-    GBDPCG_CLUSTER_N(GBDPCG_X)
+    GBDPCG_CLUSTER_SHAPES(GBDPCG_X)
 #undef GBDPCG_X
-    return (size_t)(dev.num_cus / 2) * elems * sizeof(float);
+    return (size_t)(dev.num_cus / 2) * bytes;
 }
 
 template <typename T>
 bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
 {
-    if constexpr (sizeof(T) == 4) {
-        const uint32_t H = cluster_members<T>(a.n, a.N);
-        if (H == 0 || !a.cluster_ws || a.symmetric) return false;
-        if ((reinterpret_cast<uintptr_t>(a.S) % 8) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 8)) return false;
-        uint32_t clusters = (uint32_t)dev.num_cus / H;   // one workgroup per CU: a cluster's members are resident together
-        if (clusters > a.batch) clusters = a.batch;
-        if (clusters == 0) return false;
-        const uint32_t rounds = (a.batch + clusters - 1) / clusters;
-        // a tag = {launch number, epoch}: the epochs of a launch take the low epoch_bits of its 32 bits
-        const double epochs = 2.0 + (double)rounds * (2.0 * a.max_iter + 4.0);
-        if (epochs >= (double)(1u << kClEpochBits)) return false;
-        const uint32_t C = (a.N + H - 1) / H;
-        uint32_t spin_limit = 1u << 21;      // polls before a hand-off is given up (~1 us per poll: about two seconds)
-        uint32_t drop_block = 0xffffffffu;
+    const uint32_t H = cluster_members<T>(a.n, a.N);
+    if (H == 0 || !a.cluster_ws || a.symmetric) return false;
+    if ((reinterpret_cast<uintptr_t>(a.S) % 8) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 8)) return false;
+    uint32_t clusters = (uint32_t)dev.num_cus / H;   // one workgroup per CU: a cluster's members are resident together
+    if (clusters > a.batch) clusters = a.batch;
+    if (clusters == 0) return false;
+    const uint32_t rounds = (a.batch + clusters - 1) / clusters;
+    // a tag = {launch number, epoch}: the epochs of a launch take the low kClEpochBits of its 32 bits
+    const double epochs = 2.0 + (double)rounds * (2.0 * a.max_iter + 4.0);
+    if (epochs >= (double)(1u << kClEpochBits)) return false;
+    const uint32_t C = (a.N + H - 1) / H;
+    uint32_t spin_limit = 1u << 21;      // polls before a hand-off is given up (~1 us per poll: about two seconds)
+    uint32_t drop_block = 0xffffffffu;
 #ifdef GBDPCG_TEST_HOOKS
-        // variants/libgbdpcg_hooks.so only (tests/test_gpu_cluster.py): a short bound, and a workgroup that never publishes
-        if (const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT")) spin_limit = (uint32_t)strtoul(e, nullptr, 10);
-        if (const char *e = getenv("GBDPCG_CLUSTER_DROP_WG")) drop_block = (uint32_t)strtoul(e, nullptr, 10);
-        const bool rescue_off = getenv("GBDPCG_RESCUE_OFF") != nullptr;   // show a test what a cluster that gave up leaves behind
+    // variants/libgbdpcg_hooks.so only (tests/test_gpu_cluster.py): a short bound, and a workgroup that never publishes
+    if (const char *e = getenv("GBDPCG_CLUSTER_SPIN_LIMIT")) spin_limit = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char *e = getenv("GBDPCG_CLUSTER_DROP_WG")) drop_block = (uint32_t)strtoul(e, nullptr, 10);
+    const bool rescue_off = getenv("GBDPCG_RESCUE_OFF") != nullptr;   // show a test what a cluster that gave up leaves behind
 #else
-        const bool rescue_off = false;
+    const bool rescue_off = false;
 #endif
-        PcgArgs<T> ka = a;
-        ka.rescue_off = rescue_off;
-        // coalesced LDS-DMA tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
-        static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
-        const bool staged = !no_staging && !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
-        static const bool no_plain = getenv("GBDPCG_CLUSTER_NO_PLAIN") != nullptr;   // tuning runs: always sc1 stores
-        bool launched = false;
-#define GBDPCG_X(NN)                                                                                                     \
-        if (a.n == NN) {                                                                                                 \
-            auto kern = staged ? pcg_cluster_kernel<NN, 2, true> : pcg_cluster_kernel<NN, 2, false>;                     \
-            const size_t tail = (size_t)ClusterTail<NN>::COLS * 512 * sizeof(float2);                                   \
-            const size_t lds = staged ? (dense_stage_lds_bytes<NN, 2>() > tail ? dense_stage_lds_bytes<NN, 2>() : tail) : tail; \
+    PcgArgs<T> ka = a;
+    ka.rescue_off = rescue_off;
+    // coalesced LDS-DMA tile loads need 16-byte aligned matrices (every hipMalloc'ed buffer is)
+    static const bool no_staging = getenv("GBDPCG_CLUSTER_DIRECT_LOADS") != nullptr;   // tuning runs only
+    const bool aligned16 = !((reinterpret_cast<uintptr_t>(a.S) | reinterpret_cast<uintptr_t>(a.Pinv)) % 16);
+    static const bool no_plain = getenv("GBDPCG_CLUSTER_NO_PLAIN") != nullptr;   // tuning runs: always sc1 stores
+    bool launched = false;
+#define GBDPCG_X(TT, NN, VV)                                                                                             \
+    if constexpr (sizeof(T) == sizeof(TT)) {                                                                             \
+        if (a.n == NN && !launched) {                                                                                    \
+            constexpr bool can_stage = DenseStage<TT, NN, VV>::OK;                                                       \
+            const bool staged = can_stage && !no_staging && aligned16;                                                   \
+            const size_t tail = (size_t)ClusterTail<TT, NN>::COLS * 512 * 8;                                \
+            size_t lds = tail;                                                                                           \
+            void (*kern)(PcgArgs<T>, unsigned char *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, bool) =          \
+                pcg_cluster_kernel<T, NN, VV, false>;                                                                    \
+            if constexpr (can_stage) {                                                                                   \
+                if (staged) {                                                                                            \
+                    kern = pcg_cluster_kernel<T, NN, VV, true>;                                                          \
+                    if (dense_stage_lds_bytes<TT, NN, VV>() > lds) lds = dense_stage_lds_bytes<TT, NN, VV>();            \
+                }                                                                                                        \
+            }                                                                                                            \
             /* on every launch, like the other launchers: HIP keeps the attribute per device */                          \
             if (lds) {                                                                                                   \
                 *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -676,15 +769,13 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
             hipLaunchKernelGGL(kern, dim3(clusters * H), dim3(512), lds, s, ka, static_cast<unsigned char *>(a.cluster_ws), H, C, \
                                clusters, spin_limit, drop_block, no_plain);                                              \
             launched = true;                                                                                             \
-        }
-        GBDPCG_CLUSTER_N(GBDPCG_X)
-#undef GBDPCG_X
-        if (!launched) return false;
-        *err = hipGetLastError();
-        return true;
-    } else {
-        return false;
+        }                                                                                                                \
     }
+    GBDPCG_CLUSTER_SHAPES(GBDPCG_X)
+#undef GBDPCG_X
+    if (!launched) return false;
+    *err = hipGetLastError();
+    return true;
 }
 
 template uint32_t cluster_members<float>(uint32_t, uint32_t);

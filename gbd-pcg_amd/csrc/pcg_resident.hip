@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) GBDPCG_RES_OCC_ATTR void pcg_resident_kernel(P
         if constexpr (STAGED) {
             // the staging buffers sit behind the mirrors and the reduction words in dynamic LDS (16-byte aligned)
             float *stage = reinterpret_cast<float *>(smem_raw) + stage_offset_floats;
-            dense_staged_load<NCT, V>(S, P, N, dc, wave, lane, 0u, N, stage, tS, tP, [] {});
+            dense_staged_load<T, NCT, V>(S, P, N, dc, wave, lane, 0u, N, reinterpret_cast<unsigned char *>(stage), tS, tP, [] {});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
             dense_load<T, NCT, V>(S, N, dc, tS);
@@ -254,7 +254,7 @@ static bool launch_pcg_resident_n(const DeviceInfo &dev, const PcgArgs<T> &a, hi
         if (staged) {
             uint32_t grid = (uint32_t)dev.num_cus;  // one resident workgroup owns a CU's register file
             if (grid > a.batch) grid = a.batch;
-            lds = (lds + 15) / 16 * 16 + dense_stage_lds_bytes<14, RV>();
+            lds = (lds + 15) / 16 * 16 + dense_stage_lds_bytes<T, 14, RV>();
             auto kern = pcg_resident_kernel<T, 14, RV, true>;
             *err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (*err != hipSuccess) return true;

@@ -46,8 +46,9 @@ def unsymmetrize(M, n, N, B, every=1):
 
 
 def run(solver, n, N, B, S, Pinv, gamma, lam0=None, tol=1e-6, max_iter=100, symmetric=0):
-    assert solver.cluster_members(4, n, N) >= 2, "shape has no cluster form"
-    assert solver.choose_path(4, n, N, B) == binding.PATH_FUSED
+    es = np.dtype(S.dtype).itemsize
+    assert solver.cluster_members(es, n, N) >= 2, "shape has no cluster form"
+    assert solver.choose_path(es, n, N, B) == binding.PATH_FUSED
     solver.set_symmetric(symmetric)
     try:
         dS, dP, dg = dev(S), dev(Pinv), dev(gamma)
@@ -76,12 +77,16 @@ def test_cluster_shapes(solver):
     assert solver.cluster_members(4, 14, 128) == 2 and solver.cluster_members(4, 14, 144) == 2
     assert solver.cluster_members(4, 14, 145) == 3 and solver.cluster_members(4, 14, 288) == 4
     assert solver.cluster_members(4, 14, 72) == 0      # one workgroup holds it (pcg_resident.hip)
-    assert solver.cluster_members(4, 14, 289) == 0 and solver.cluster_members(8, 14, 128) == 0
+    assert solver.cluster_members(4, 14, 289) == 0
     assert solver.cluster_members(4, 36, 128) == 0
     # stateSize 12 (round 3): 80 knots per workgroup
     assert solver.cluster_members(4, 12, 80) == 0 and solver.cluster_members(4, 12, 81) == 2 and solver.cluster_members(4, 12, 128) == 2
     assert solver.cluster_members(4, 12, 161) == 3 and solver.cluster_members(4, 12, 320) == 4 and solver.cluster_members(4, 12, 321) == 0
-    assert solver.cluster_members(8, 12, 128) == 0 and solver.cluster_members(4, 13, 128) == 0 and solver.cluster_members(4, 18, 128) == 0
+    assert solver.cluster_members(8, 12, 128) == 0 and solver.cluster_members(4, 18, 128) == 0
+    # one row per lane: stateSize 13 in fp32 and the BASELINE block size in fp64 (32 knots per workgroup)
+    assert solver.cluster_members(4, 13, 32) == 0 and solver.cluster_members(4, 13, 33) == 2 and solver.cluster_members(4, 13, 128) == 4
+    assert solver.cluster_members(8, 14, 32) == 0 and solver.cluster_members(8, 14, 64) == 2 and solver.cluster_members(8, 14, 128) == 4
+    assert solver.cluster_members(8, 14, 129) == 0 and solver.cluster_members(8, 36, 64) == 0
     # ... 8, 10 and 16: 128, 96 and 64 knots per workgroup
     assert solver.cluster_members(4, 8, 128) == 0 and solver.cluster_members(4, 8, 256) == 2 and solver.cluster_members(4, 8, 512) == 4
     assert solver.cluster_members(4, 10, 96) == 0 and solver.cluster_members(4, 10, 128) == 2
@@ -120,6 +125,35 @@ def test_cluster_other_state_sizes(solver, orc, n, N, B):
     ob = orc.pcg_batch(n, N, B, S, Pi, g, tol=0.0, max_iter=5, lambda0=lam0, nthreads=8)
     out = run(solver, n, N, B, S, Pi, g, lam0=lam0, tol=0.0, max_iter=5)
     check(out, ob, {"gamma": g}, B, ltol=2e-6)
+
+
+@pytest.mark.parametrize("n,dtype,N,B", [(14, np.float64, 128, 5), (14, np.float64, 33, 3), (14, np.float64, 64, 140), (14, np.float64, 65, 2),
+                                         (14, np.float64, 100, 70), (14, np.float64, 127, 1), (13, np.float32, 128, 5), (13, np.float32, 33, 3),
+                                         (13, np.float32, 64, 140), (13, np.float32, 97, 70), (13, np.float32, 100, 2)])
+def test_cluster_one_row_per_lane(solver, orc, n, dtype, N, B):
+    """One row per lane: the BASELINE block size in fp64 (14 lanes per knot, 32 knots per workgroup, the
+    hand-off words carry both halves of an fp64 value under their own tags) and stateSize 13 in fp32 (13 lanes per knot, direct
+    tile loads, one accumulator chain per row).  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
+    the default symmetric mode (general RESIDENT beats symmetric STREAMING); then a fixed count from a warm start."""
+    base = min(B, 6)
+    d = synth.gen_numpy(n, N, seed=300 + N + n, batch=base, dtype=dtype)
+    idx = np.arange(B) % base
+    S, Pi = d["S"][idx], d["Pinv"][idx]
+    g = (d["gamma"][idx] * (1.0 + 0.01 * (np.arange(B) // base))[:, None]).astype(dtype)
+    ltol = 1e-10 if dtype == np.float64 else 1e-6
+    vtol = 1e-9 if dtype == np.float64 else 2e-5
+    ob = orc.pcg_batch(n, N, B, S, Pi, g, tol=1e-6, max_iter=100, nthreads=8)
+    for mode in (0, 2):
+        out = run(solver, n, N, B, S, Pi, g, symmetric=mode)
+        check(out, ob, {"gamma": g}, B, ltol=ltol, vtol=vtol)
+    lam0 = (0.1 * np.random.default_rng(N).standard_normal((B, n * N))).astype(dtype)
+    ob = orc.pcg_batch(n, N, B, S, Pi, g, tol=0.0, max_iter=5, lambda0=lam0, nthreads=8)
+    out = run(solver, n, N, B, S, Pi, g, lam0=lam0, tol=0.0, max_iter=5)
+    check(out, ob, {"gamma": g}, B, ltol=2 * ltol, vtol=vtol)
+    # without a preconditioner, fixed count
+    ob = orc.pcg_batch(n, N, B, S, None, g, tol=0.0, max_iter=4, lambda0=lam0, nthreads=8)
+    out = run(solver, n, N, B, S, None, g, lam0=lam0, tol=0.0, max_iter=4)
+    check(out, ob, {"gamma": g}, B, ltol=20 * ltol, vtol=10 * vtol)
 
 
 @pytest.mark.parametrize("N,B", [(250, 70), (150, 100), (288, 64), (100, 130)])
