@@ -611,6 +611,8 @@ __global__ __launch_bounds__(kPinvThreads) void pinv_stair_reg_kernel(uint32_t N
 // follows needs no symmetry test of its own (gbdpcg_form_pinv_solve_*).  Written unconditionally.
 // S_SYM: the caller KNOWS L_{k+1} == R_k^T in S (gbdpcg_kkt_step_*): L is never read.  A compile-time switch: as a kernel argument
 // the same test cost the ordinary path 40 us of 150 (the compiler's schedule of the pair loop changed).
+// (Held to 64 registers -- eight waves per SIMD instead of six, amdgpu_waves_per_eu(8) -- it spills 10 registers and takes 208 us
+// instead of 162 for the 1024 x 128 batch: measured in round 3, dropped.)
 template <typename T, int NCT, bool S_SYM>
 __global__ __launch_bounds__(kPinvThreads) void pinv_stair_fused_kernel(uint32_t N, uint32_t chunks, const T *__restrict__ S,
                                                                        T *__restrict__ Pinv, uint8_t *__restrict__ verdicts)

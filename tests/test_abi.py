@@ -73,3 +73,17 @@ def test_csr_to_bt_roundtrip(orc, dtype):
     csr = sp.csr_matrix(A)
     with pytest.raises(binding.GbdPcgError):
         binding.csr_to_bt(n, N, csr.indptr, csr.indices, csr.data.astype(dtype))
+
+
+def test_shipped_library_has_no_fault_injection_hooks():
+    """The hooks that make a workgroup of the cluster / persistent kernels vanish or arrive late, shorten the spin bound or
+    switch the in-kernel rescue off exist in csrc/variants/libgbdpcg_hooks.so only (-DGBDPCG_TEST_HOOKS):
+    the shipped library must not even contain their names."""
+    from gbd_pcg_amd import binding
+    blob = open(binding.LIB_PATH, "rb").read()
+    for name in (b"DROP_WG", b"SPIN_LIMIT", b"RESCUE_OFF", b"HOLD_US"):
+        assert name not in blob, name
+    hooks = os.path.join(os.path.dirname(binding.LIB_PATH), "variants", "libgbdpcg_hooks.so")
+    assert os.path.exists(hooks), "make -C gbd-pcg_amd/csrc builds it next to the shipped library"
+    hb = open(hooks, "rb").read()
+    assert b"GBDPCG_CLUSTER_DROP_WG" in hb and b"GBDPCG_PERSIST_HOLD_US" in hb and b"GBDPCG_RESCUE_OFF" in hb
