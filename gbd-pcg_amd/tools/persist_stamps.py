@@ -46,7 +46,7 @@ def main():
     # hop latency: every workgroup's real-time clock (100 MHz, common to the chip) at its publish and at the end of its sweep
     K = int(os.environ.get("GBDPCG_PERSIST_K", "2"))
     Wn = (N + K - 1) // K
-    words = 16 + 2 * N * 16 + 2 * N * 2 * n * 2          # ctrl + partial slots (128-byte stride) + first halo region (fp64), in u64
+    words = 32 + 2 * N * 16 + 2 * N * 2 * n * 2          # ctrl (kPersistCtrl) + partial slots (128-byte stride) + first halo region (fp64), in u64
     xs = (ctypes.c_uint64 * (2 * Wn))()
     assert hip.hipMemcpy(xs, ctypes.c_void_p(ptr + 8 * words), 8 * 2 * Wn, 2) == 0
     pub = [xs[2 * i] for i in range(Wn)]
