@@ -83,6 +83,9 @@ __device__ __forceinline__ double dense_tail_row(const double &v, int) { return 
 __device__ __forceinline__ float dense_tail_row(const float2 &v, int j) { return j == 0 ? v.x : v.y; }
 __device__ __forceinline__ double dense_tail_row(const double2 &v, int j) { return j == 0 ? v.x : v.y; }
 
+#ifndef GBDPCG_DENSE_AH
+#define GBDPCG_DENSE_AH 2   // steps ahead of its use an operand pair of the three-chain product is requested (1: round 2; 2 measured 1-1.6 % faster on the cluster shapes and 12 registers lighter at n = 14; 3: no further gain)
+#endif
 template <typename T, int NCT, int V, int CHAINS = 1, int TAIL = 0>
 __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T *X, const DenseCtx<T, NCT, V> &dc,
                                          T (&acc)[V], const typename DenseTailElem<T, V>::type *tail = nullptr, uint32_t tstride = 0)
@@ -125,54 +128,53 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
         // The three blocks side by side: independent work in every step.  The steps are pinned in source order with the
         // operands of the next one requested before the fma's of this one: left to itself hipcc hoists all 21 operand reads
         // to the top (42 more live registers next to 168 of matrix data) and spills elsewhere in the kernel.
-        P2 xv[3], nx[3];
-        TV tv[2], nt[2];
+        // AH steps ahead (GBDPCG_DENSE_AH): an LDS read issued one step before its use is not back in time -- a step is six packed
+        // fmas per wave -- and every step then stalls on it (measured in pcg_cluster.hip: 950 cycles per product, 7 steps).
+        constexpr uint32_t STEPS = Dg::N_ / 2, AH = GBDPCG_DENSE_AH < STEPS ? GBDPCG_DENSE_AH : STEPS;
+        P2 xq[STEPS][3];
+        TV tq[STEPS][2];
+        auto request = [&](uint32_t st) __attribute__((always_inline)) {
+            const uint32_t c = 2 * st;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) xv[q] = xk[(q * Dg::N_) / 2];
-        if constexpr (TAIL >= (int)Dg::N_) {
-            tv[0] = tail[0];
-            tv[1] = tail[tstride];
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < Dg::N_; c += 2) {
-            if (c + 2 < Dg::N_) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) nx[q] = xk[(q * Dg::N_ + c + 2) / 2];
-                if constexpr (TAIL > 0) {
-                    if (c + 2 >= Dg::N_ - TAIL) {   // the next step's two columns of the last block come from LDS
-                        nt[0] = tail[(c + 2 - (Dg::N_ - TAIL)) * tstride];
-                        nt[1] = tail[(c + 3 - (Dg::N_ - TAIL)) * tstride];
-                    }
+            for (int q = 0; q < 3; ++q) xq[st][q] = xk[(q * Dg::N_ + c) / 2];
+            if constexpr (TAIL > 0) {
+                if (c >= Dg::N_ - TAIL) {   // this step's two columns of the last block come from LDS
+                    tq[st][0] = tail[(c - (Dg::N_ - TAIL)) * tstride];
+                    tq[st][1] = tail[(c + 1 - (Dg::N_ - TAIL)) * tstride];
                 }
             }
+        };
+#pragma unroll
+        for (uint32_t st = 0; st < AH; ++st) request(st);
+#pragma unroll
+        for (uint32_t st = 0; st < STEPS; ++st) {
+            const uint32_t c = 2 * st;
+            if (st + AH < STEPS) request(st + AH);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const bool from_lds = TAIL > 0 && q == 2 && c >= Dg::N_ - TAIL;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const T m = from_lds ? dense_tail_row(tv[0], j) : tl.a[q * Dg::N_ + c][j];
-                    part[q][j] = fma_t(m, xv[q].x, part[q][j]);
+                    const T m = from_lds ? dense_tail_row(tq[st][0], j) : tl.a[q * Dg::N_ + c][j];
+                    part[q][j] = fma_t(m, xq[st][q].x, part[q][j]);
                 }
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const T m = from_lds ? dense_tail_row(tv[1], j) : tl.a[q * Dg::N_ + c + 1][j];
-                    part[q][j] = fma_t(m, xv[q].y, part[q][j]);
+                    const T m = from_lds ? dense_tail_row(tq[st][1], j) : tl.a[q * Dg::N_ + c + 1][j];
+                    part[q][j] = fma_t(m, xq[st][q].y, part[q][j]);
                 }
             }
-            if constexpr (TAIL > 0 || sizeof(T) == 8) {
-                // with tail operands coming out of LDS (and in fp64, where everything is twice as wide) the accumulators are anchored here as well: the sched_barrier alone orders
-                // the LDS reads, and hipcc then sinks every fma of the product below the last of them (all operands live at
-                // once: 80 registers, and matrix registers spilled inside the iteration)
+            if constexpr (TAIL > 0 || sizeof(T) == 8 || (GBDPCG_DENSE_AH > 1)) {
+                // with tail operands coming out of LDS (and in fp64, where everything is twice as wide, and with operands requested
+                // more than a step ahead) the accumulators are anchored here as well: the sched_barrier alone orders the LDS reads,
+                // and hipcc then sinks every fma of the product below the last of them (all operands live at once: 80
+                // registers, and matrix registers spilled inside the iteration)
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
                     for (int j = 0; j < V; ++j) asm volatile("" : "+v"(part[q][j]));
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) xv[q] = nx[q];
-            tv[0] = nt[0];
-            tv[1] = nt[1];
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = (part[0][j] + part[1][j]) + part[2][j];
