@@ -82,7 +82,7 @@ def test_cluster_shapes(solver):
     # stateSize 12 (round 3): 80 knots per workgroup
     assert solver.cluster_members(4, 12, 80) == 0 and solver.cluster_members(4, 12, 81) == 2 and solver.cluster_members(4, 12, 128) == 2
     assert solver.cluster_members(4, 12, 161) == 3 and solver.cluster_members(4, 12, 320) == 4 and solver.cluster_members(4, 12, 321) == 0
-    assert solver.cluster_members(8, 12, 128) == 0 and solver.cluster_members(4, 18, 128) == 0
+    assert solver.cluster_members(4, 18, 128) == 0
     # one row per lane: stateSize 13 in fp32 and the BASELINE block size in fp64 (32 knots per workgroup)
     assert solver.cluster_members(4, 13, 32) == 0 and solver.cluster_members(4, 13, 33) == 2 and solver.cluster_members(4, 13, 128) == 4
     assert solver.cluster_members(8, 14, 32) == 0 and solver.cluster_members(8, 14, 64) == 2 and solver.cluster_members(8, 14, 128) == 4
@@ -91,6 +91,11 @@ def test_cluster_shapes(solver):
     assert solver.cluster_members(4, 8, 128) == 0 and solver.cluster_members(4, 8, 256) == 2 and solver.cluster_members(4, 8, 512) == 4
     assert solver.cluster_members(4, 10, 96) == 0 and solver.cluster_members(4, 10, 128) == 2
     assert solver.cluster_members(4, 16, 64) == 0 and solver.cluster_members(4, 16, 128) == 2 and solver.cluster_members(4, 16, 256) == 4
+    # one row per lane at the other block sizes: fp64 8 / 10 / 12 (64 / 48 / 40 knots per workgroup), fp32 9 / 11 / 15 (56 / 40 / 32)
+    assert solver.cluster_members(8, 12, 40) == 0 and solver.cluster_members(8, 12, 128) == 4 and solver.cluster_members(8, 12, 161) == 0
+    assert solver.cluster_members(8, 10, 48) == 0 and solver.cluster_members(8, 10, 128) == 3 and solver.cluster_members(8, 8, 128) == 2
+    assert solver.cluster_members(4, 9, 56) == 0 and solver.cluster_members(4, 9, 128) == 3 and solver.cluster_members(4, 11, 128) == 4
+    assert solver.cluster_members(4, 15, 32) == 0 and solver.cluster_members(4, 15, 128) == 4 and solver.cluster_members(4, 15, 129) == 0
 
 
 @pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (73, 2), (100, 9), (144, 3), (145, 2), (200, 4), (216, 1), (217, 2), (288, 3)])
@@ -129,11 +134,16 @@ def test_cluster_other_state_sizes(solver, orc, n, N, B):
 
 @pytest.mark.parametrize("n,dtype,N,B", [(14, np.float64, 128, 5), (14, np.float64, 33, 3), (14, np.float64, 64, 140), (14, np.float64, 65, 2),
                                          (14, np.float64, 100, 70), (14, np.float64, 127, 1), (13, np.float32, 128, 5), (13, np.float32, 33, 3),
-                                         (13, np.float32, 64, 140), (13, np.float32, 97, 70), (13, np.float32, 100, 2)])
+                                         (13, np.float32, 64, 140), (13, np.float32, 97, 70), (13, np.float32, 100, 2),
+                                         (12, np.float64, 128, 5), (12, np.float64, 41, 3), (12, np.float64, 160, 2), (12, np.float64, 100, 70),
+                                         (10, np.float64, 49, 2), (10, np.float64, 128, 70), (10, np.float64, 192, 2), (8, np.float64, 65, 3),
+                                         (8, np.float64, 200, 70), (8, np.float64, 256, 2), (9, np.float32, 57, 3), (9, np.float32, 128, 70),
+                                         (9, np.float32, 224, 2), (11, np.float32, 41, 2), (11, np.float32, 128, 70), (11, np.float32, 160, 3),
+                                         (15, np.float32, 33, 3), (15, np.float32, 100, 70), (15, np.float32, 128, 5)])
 def test_cluster_one_row_per_lane(solver, orc, n, dtype, N, B):
     """One row per lane: the BASELINE block size in fp64 (14 lanes per knot, 32 knots per workgroup, the
     hand-off words carry both halves of an fp64 value under their own tags) and stateSize 13 in fp32 (13 lanes per knot, direct
-    tile loads, one accumulator chain per row).  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
+    tile loads, one accumulator chain per row); the same template at stateSize 8, 10, 12 in fp64 and 9, 11, 15 in fp32.  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
     the default symmetric mode (general RESIDENT beats symmetric STREAMING); then a fixed count from a warm start."""
     base = min(B, 6)
     d = synth.gen_numpy(n, N, seed=300 + N + n, batch=base, dtype=dtype)
