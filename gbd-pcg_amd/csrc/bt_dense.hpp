@@ -48,7 +48,8 @@ template <typename T, int NCT, int V> struct DenseCtx {
     }
 };
 
-template <typename T, int NCT, int V>
+// (C0, C1: the columns [C0, C1) of the block-row only -- pcg_cluster.hip brings a tile in in two parts where half of it goes on to LDS)
+template <typename T, int NCT, int V, uint32_t C0 = 0, uint32_t C1 = 3 * (NCT > 0 ? NCT : 2)>
 __device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, const DenseCtx<T, NCT, V> &dc,
                                            DenseTile<T, NCT, V> &tl)
 {
@@ -57,7 +58,7 @@ __device__ __forceinline__ void dense_load(const T *__restrict__ M, uint32_t N, 
     const T *src = M + (size_t)k * 3 * Dg::N_ * Dg::N_ + dc.rp * V;
     const uint32_t c_lo = dc.k == 0 ? Dg::N_ : 0u, c_hi = dc.k == N - 1 ? 2 * Dg::N_ : 3 * Dg::N_;
 #pragma unroll
-    for (uint32_t c = 0; c < Dg::COLS; ++c) {
+    for (uint32_t c = C0; c < C1; ++c) {
         T v[V];
         VecIO<T, V>::load(src + c * Dg::N_, v);
         const bool keep = dc.live && c >= c_lo && c < c_hi;
@@ -88,13 +89,17 @@ __device__ __forceinline__ double dense_tail_row(const double2 &v, int j) { retu
 #endif
 template <typename T, int NCT, int V, int CHAINS = 1, int TAIL = 0>
 __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T *X, const DenseCtx<T, NCT, V> &dc,
-                                         T (&acc)[V], const typename DenseTailElem<T, V>::type *tail = nullptr, uint32_t tstride = 0)
+                                         T (&acc)[V], const typename DenseTailElem<T, V>::type *tail = nullptr, uint32_t tstride = 0,
+                                         const typename DenseTailElem<T, V>::type *tail_d = nullptr)
 {
     using Dg = DenseGeom<T, NCT, V>;
     using P2 = typename VecOf<T, 2>::type;
     using TV = typename DenseTailElem<T, V>::type;
     static_assert(CHAINS == 1 || (CHAINS == 3 && Dg::N_ % 2 == 0), "one chain, or one per block (whole x pairs per block)");
-    static_assert(TAIL == 0 || (CHAINS == 3 && V <= 2 && TAIL % 2 == 0 && TAIL <= (int)Dg::N_), "tail columns: whole pairs of the last block");
+    static_assert(TAIL == 0 || (CHAINS == 3 && V <= 2 && TAIL % 2 == 0 && TAIL <= 2 * (int)Dg::N_), "tail columns: whole pairs of the last block (and of the one before it)");
+    // tail columns of the last block (R) and of the middle one (D): TAIL > n puts all of R and the last TAIL - n columns of D in LDS,
+    // the D part behind its own pointer (`tail_d`, same stride)
+    constexpr int TAIL_R = TAIL < (int)Dg::N_ ? TAIL : (int)Dg::N_, TAIL_D = TAIL - TAIL_R;
     const uint32_t kl = dc.live ? dc.kl : 0u;
     const P2 *xk = reinterpret_cast<const P2 *>(X + kl * Dg::N_);  // column c of local row kl multiplies X[kl*n + c]
     T part[CHAINS][V];
@@ -132,15 +137,21 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
         // fmas per wave -- and every step then stalls on it (measured in pcg_cluster.hip: 950 cycles per product, 7 steps).
         constexpr uint32_t STEPS = Dg::N_ / 2, AH = GBDPCG_DENSE_AH < STEPS ? GBDPCG_DENSE_AH : STEPS;
         P2 xq[STEPS][3];
-        TV tq[STEPS][2];
+        TV tq[STEPS][2], td[STEPS][2];
         auto request = [&](uint32_t st) __attribute__((always_inline)) {
             const uint32_t c = 2 * st;
 #pragma unroll
             for (int q = 0; q < 3; ++q) xq[st][q] = xk[(q * Dg::N_ + c) / 2];
             if constexpr (TAIL > 0) {
-                if (c >= Dg::N_ - TAIL) {   // this step's two columns of the last block come from LDS
-                    tq[st][0] = tail[(c - (Dg::N_ - TAIL)) * tstride];
-                    tq[st][1] = tail[(c + 1 - (Dg::N_ - TAIL)) * tstride];
+                if (c >= Dg::N_ - TAIL_R) {   // this step's two columns of the last block come from LDS
+                    tq[st][0] = tail[(c - (Dg::N_ - TAIL_R)) * tstride];
+                    tq[st][1] = tail[(c + 1 - (Dg::N_ - TAIL_R)) * tstride];
+                }
+            }
+            if constexpr (TAIL_D > 0) {
+                if (c >= Dg::N_ - TAIL_D) {   // ... and of the middle one
+                    td[st][0] = tail_d[(c - (Dg::N_ - TAIL_D)) * tstride];
+                    td[st][1] = tail_d[(c + 1 - (Dg::N_ - TAIL_D)) * tstride];
                 }
             }
         };
@@ -152,15 +163,15 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
             if (st + AH < STEPS) request(st + AH);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const bool from_lds = TAIL > 0 && q == 2 && c >= Dg::N_ - TAIL;
+                const bool from_r = TAIL > 0 && q == 2 && c >= Dg::N_ - TAIL_R, from_d = TAIL_D > 0 && q == 1 && c >= Dg::N_ - TAIL_D;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const T m = from_lds ? dense_tail_row(tq[st][0], j) : tl.a[q * Dg::N_ + c][j];
+                    const T m = from_r ? dense_tail_row(tq[st][0], j) : from_d ? dense_tail_row(td[st][0], j) : tl.a[q * Dg::N_ + c][j];
                     part[q][j] = fma_t(m, xq[st][q].x, part[q][j]);
                 }
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const T m = from_lds ? dense_tail_row(tq[st][1], j) : tl.a[q * Dg::N_ + c + 1][j];
+                    const T m = from_r ? dense_tail_row(tq[st][1], j) : from_d ? dense_tail_row(td[st][1], j) : tl.a[q * Dg::N_ + c + 1][j];
                     part[q][j] = fma_t(m, xq[st][q].y, part[q][j]);
                 }
             }
@@ -207,7 +218,7 @@ template <typename T, int NCT, int V>
 __device__ __forceinline__ void dense_stage_issue(const T *base, uint32_t lane, uint32_t nk, uint32_t lds_addr)
 {
     using St = DenseStage<T, NCT, V>;
-    static_assert(St::OK && St::LOADS >= 4 && St::LOADS <= 8, "stage sizes written out: 4 .. 8 loads");
+    static_assert(St::OK && St::LOADS >= 4 && St::LOADS <= 9, "stage sizes written out: 4 .. 9 loads");
     uint32_t lo = lane;
     asm volatile("" : "+v"(lo));
     uint32_t rel[St::LOADS];
@@ -288,6 +299,24 @@ __device__ __forceinline__ void dense_stage_issue(const T *base, uint32_t lane, 
                      : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "v"(rel[7]), "s"(lds_addr)
                      : "memory", "scc");
     }
+    else if constexpr (St::LOADS == 9) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"   // the reads of the stage that used this buffer are done
+                     "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %1\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(rel[0]), "v"(rel[1]), "v"(rel[2]), "v"(rel[3]), "v"(rel[4]), "v"(rel[5]), "v"(rel[6]), "v"(rel[7]), "v"(rel[8]),
+                       "s"(lds_addr)
+                     : "memory", "scc");
+    }
 }
 // all but the youngest `newer` stages (LOADS loads each) of this wave have landed
 template <typename T, int NCT, int V, int NEWER> __device__ __forceinline__ void dense_stage_wait()
@@ -327,7 +356,8 @@ template <typename T, int NCT, int V> constexpr size_t dense_stage_lds_bytes() {
 // buffers.  `between` is called once, behind the first two stage issues: loads requested there (vectors) are younger than
 // two stages, which makes the first wait stricter than it has to be, never laxer.  tP is defined on every path (zeros
 // without a preconditioner): a conditionally loaded tile is carried around the caller's problem loop by hipcc, all of it.
-// P_TAIL (0 or n): the R block of Pinv is not picked into tP but left in LDS for dense_mv's TAIL form -- in the wave's OWN
+// P_TAIL (0, n or 2n; 2n: the D block as well, re-laid inside the first buffer, the R block inside the second -- dense_mv's tail_d
+// and tail): the R block of Pinv is not picked into tP but left in LDS for dense_mv's TAIL form -- in the wave's OWN
 // first staging buffer (the last stage arrives in the second one, and a wave's LDS operations execute in order), one
 // 8-byte element per lane and column, lane-contiguous: tail[c * 64 + lane].  The wave must not stage anything else before
 // its solve is over.
@@ -336,7 +366,8 @@ __device__ __forceinline__ void dense_staged_load(const T *S, const T *P, uint32
                                                   uint32_t wave, uint32_t lane, uint32_t k_lo, uint32_t cnt, unsigned char *stage,
                                                   DenseTile<T, NCT, V> &tS, DenseTile<T, NCT, V> &tP, Between between)
 {
-    static_assert(P_TAIL == 0 || (P_TAIL == NCT && (size_t)NCT * 64 * 8 <= DenseStage<T, NCT, V>::BYTES), "the whole R block, inside one staging buffer");
+    static_assert(P_TAIL == 0 || ((P_TAIL == NCT || P_TAIL == 2 * NCT) && (size_t)NCT * 64 * 8 <= DenseStage<T, NCT, V>::BYTES),
+                  "the whole R block (or the D and the R block), each inside one staging buffer");
     using Dg = DenseGeom<T, NCT, V>;
     constexpr uint32_t n = NCT;
     // this wave's knots [kw, kw + nk)
@@ -365,10 +396,27 @@ __device__ __forceinline__ void dense_staged_load(const T *S, const T *P, uint32
         dense_stage_pick<T, NCT, V, 0>(buf1, dc, b9, N, tP);
         dense_stage_issue<T, NCT, V>(Pw + 2 * n * n, lane, nk, lds1);
         dense_stage_wait<T, NCT, V, 1>();
-        dense_stage_pick<T, NCT, V, 1>(buf0, dc, b9, N, tP);
+        // One block from the staging layout to the tail layout (tail[c * 64 + lane], one 8-byte element per lane and column) INSIDE
+        // its buffer: every read of the wave is issued before its first write, and a wave's LDS operations execute in order.
+        auto in_place = [&](unsigned char *buf, bool keep) __attribute__((always_inline)) {
+            const dense_float2_alias *src = reinterpret_cast<const dense_float2_alias *>(buf + (size_t)b9 * n * n * sizeof(T) + dc.rp * 8);
+            dense_float2_alias *tail = reinterpret_cast<dense_float2_alias *>(buf) + lane;
+            float2 v[n];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (uint32_t c = 0; c < n; ++c) v[c] = src[c * n * sizeof(T) / 8];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (uint32_t c = 0; c < n; ++c) tail[c * 64] = keep ? v[c] : make_float2(0.f, 0.f);
+            asm volatile("" ::: "memory");
+        };
+        if constexpr (P_TAIL == 2 * NCT) in_place(buf0, dc.live);
+        else dense_stage_pick<T, NCT, V, 1>(buf0, dc, b9, N, tP);
         dense_stage_wait<T, NCT, V, 0>();
         if constexpr (P_TAIL == 0) {
             dense_stage_pick<T, NCT, V, 2>(buf1, dc, b9, N, tP);
+        } else if constexpr (P_TAIL == 2 * NCT) {
+            in_place(buf1, dc.live && dc.k != N - 1);   // R_{N-1} is never used; lanes without a row hold zeros
         } else {
             const bool keep = dc.live && dc.k != N - 1;   // R_{N-1} is never used; lanes without a row hold zeros
             const dense_float2_alias *src = reinterpret_cast<const dense_float2_alias *>(buf1 + (size_t)b9 * n * n * sizeof(T) + dc.rp * 8);

@@ -104,7 +104,7 @@ template <typename T> __device__ __forceinline__ T cl_partials(uint32_t w0, uint
 #define GBDPCG_CL_PTAIL 0   // columns of a lane's Pinv block-row kept in LDS instead of registers (0, 2, 4, ...): not needed since the kernel compiles without scratch; kept for A/B builds
 #endif
 template <typename T, int NCT> struct ClusterTail {
-    static constexpr int COLS = (sizeof(T) == 4 && NCT == 16) ? 16 : (sizeof(T) == 8 && NCT == 14) ? 14 : (NCT % 2 == 0 ? GBDPCG_CL_PTAIL : 0);
+    static constexpr int COLS = (sizeof(T) == 4 && NCT == 18) ? 36 : (sizeof(T) == 8 && NCT == 16) ? 32 : (sizeof(T) == 4 && NCT == 16) ? 16 : (sizeof(T) == 8 && NCT == 14) ? 14 : (NCT % 2 == 0 ? GBDPCG_CL_PTAIL : 0);
 };
 // bytes between the tails of two waves in dynamic LDS
 template <typename T, int NCT, int V, bool STAGED> struct ClusterTailBytes {
@@ -151,7 +151,14 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     TV *ptail = reinterpret_cast<TV *>(stage_raw + (size_t)wave * ClusterTailBytes<T, NCT, V, STAGED>::PER_WAVE);
-    const TV *pt_lane = ptail + lane;
+    // PTAIL <= n: columns of the R block, behind pt_lane.  PTAIL = 2n (stateSize 18): the D block behind ptd_lane (staged: re-laid inside
+    // the wave's first staging buffer) and the R block behind pt_lane (staged: inside its second buffer).
+    constexpr bool TWO = PTAIL > (int)NCT;
+    static_assert(!TWO || PTAIL == 2 * (int)NCT, "the D and the R block, whole");
+    const TV *ptd_lane = ptail + lane;
+    const TV *pt_lane = !TWO ? ptail + lane
+                        : STAGED ? reinterpret_cast<const TV *>(stage_raw + (size_t)(Dg::WAVES + wave) * ClusterTailBytes<T, NCT, V, STAGED>::PER_WAVE) + lane
+                                 : ptail + NCT * 64 + lane;
     const uint32_t grid = gridDim.x, blk = blockIdx.x;
     // cluster c, member h.  Members sit 8 blocks apart where the cluster count allows it: blocks b and b + 8 share an XCD
     // under round-robin dispatch (a hand-off inside one L2 is ~20 % shorter).  Speed only: nothing depends on placement.
@@ -420,14 +427,18 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
             request_vectors();
             dense_load<T, NCT, V>(S, N, dc, tS);
             if (P) {
-                dense_load<T, NCT, V>(P, N, dc, tP);
-                if constexpr (PTAIL > 0) {   // (direct loads: the tail goes through the registers, once per problem)
+                // (direct loads: the tail goes through the registers, once per problem -- and first, so that its registers are free
+                // again when the columns that stay arrive)
+                dense_load<T, NCT, V, Dg::COLS - PTAIL, Dg::COLS>(P, N, dc, tP);
+                if constexpr (PTAIL > 0) {
 #pragma unroll
                     for (int t = 0; t < PTAIL; ++t) {
                         if constexpr (V == 2) ptail[t * 64 + lane] = TV{tP.a[Dg::COLS - PTAIL + t][0], tP.a[Dg::COLS - PTAIL + t][1]};
                         else ptail[t * 64 + lane] = tP.a[Dg::COLS - PTAIL + t][0];
                     }
+                    asm volatile("" ::: "memory");
                 }
+                dense_load<T, NCT, V, 0, Dg::COLS - PTAIL>(P, N, dc, tP);
             } else {
 #pragma unroll
                 for (uint32_t cc = 0; cc < Dg::COLS; ++cc)
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
         // r~ = Pinv r ; p = r~ ; eta = r.r~                               (pcg.cuh:130-149)
         T eta = T(0);
         if (!failed) {
-            if (P) dense_mv<T, NCT, V, CHAINS, PTAIL>(tP, xb, dc, yv, pt_lane, 64);
+            if (P) dense_mv<T, NCT, V, CHAINS, PTAIL>(tP, xb, dc, yv, pt_lane, 64, ptd_lane);
             part = T(0);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -555,7 +566,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
             wg_barrier();
             GBDPCG_CL_STAMP(5, POLL, iter == 3 && ordinal == 0)
             // r~ = Pinv r ; eta_new = r.r~                                (pcg.cuh:180-193)
-            if (P) dense_mv<T, NCT, V, CHAINS, PTAIL>(tP, xb, dc, yv, pt_lane, 64);
+            if (P) dense_mv<T, NCT, V, CHAINS, PTAIL>(tP, xb, dc, yv, pt_lane, 64, ptd_lane);
             part = T(0);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -682,7 +693,8 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
 // chain per row).
 #define GBDPCG_CLUSTER_SHAPES(X) \
     X(float, 8, 2) X(float, 9, 1) X(float, 10, 2) X(float, 11, 1) X(float, 12, 2) X(float, 13, 1) X(float, 14, 2) X(float, 15, 1) X(float, 16, 2) \
-    X(double, 8, 1) X(double, 10, 1) X(double, 12, 1) X(double, 14, 1)
+    X(float, 18, 2) \
+    X(double, 8, 1) X(double, 10, 1) X(double, 12, 1) X(double, 14, 1) X(double, 16, 1)
 
 // General storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n / V)) knots
 // -- 72 at n = 14 in fp32) up to kClMaxH times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).

@@ -82,7 +82,6 @@ def test_cluster_shapes(solver):
     # stateSize 12 (round 3): 80 knots per workgroup
     assert solver.cluster_members(4, 12, 80) == 0 and solver.cluster_members(4, 12, 81) == 2 and solver.cluster_members(4, 12, 128) == 2
     assert solver.cluster_members(4, 12, 161) == 3 and solver.cluster_members(4, 12, 320) == 4 and solver.cluster_members(4, 12, 321) == 0
-    assert solver.cluster_members(4, 18, 128) == 0
     # one row per lane: stateSize 13 in fp32 and the BASELINE block size in fp64 (32 knots per workgroup)
     assert solver.cluster_members(4, 13, 32) == 0 and solver.cluster_members(4, 13, 33) == 2 and solver.cluster_members(4, 13, 128) == 4
     assert solver.cluster_members(8, 14, 32) == 0 and solver.cluster_members(8, 14, 64) == 2 and solver.cluster_members(8, 14, 128) == 4
@@ -96,6 +95,11 @@ def test_cluster_shapes(solver):
     assert solver.cluster_members(8, 10, 48) == 0 and solver.cluster_members(8, 10, 128) == 3 and solver.cluster_members(8, 8, 128) == 2
     assert solver.cluster_members(4, 9, 56) == 0 and solver.cluster_members(4, 9, 128) == 3 and solver.cluster_members(4, 11, 128) == 4
     assert solver.cluster_members(4, 15, 32) == 0 and solver.cluster_members(4, 15, 128) == 4 and solver.cluster_members(4, 15, 129) == 0
+    # stateSize 18: 9 lanes per knot, 56 knots per workgroup, the D and R blocks of Pinv in LDS
+    assert solver.cluster_members(4, 18, 56) == 0 and solver.cluster_members(4, 18, 128) == 3 and solver.cluster_members(4, 18, 224) == 4
+    assert solver.cluster_members(4, 18, 225) == 0 and solver.cluster_members(8, 18, 128) == 0 and solver.cluster_members(4, 20, 128) == 0
+    # fp64 at stateSize 16: 16 lanes per knot, 32 knots per workgroup, the D and R blocks of Pinv in LDS
+    assert solver.cluster_members(8, 16, 32) == 0 and solver.cluster_members(8, 16, 128) == 4 and solver.cluster_members(8, 16, 129) == 0
 
 
 @pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (73, 2), (100, 9), (144, 3), (145, 2), (200, 4), (216, 1), (217, 2), (288, 3)])
@@ -110,10 +114,11 @@ def test_cluster_vs_oracle(solver, orc, N, B):
 
 @pytest.mark.parametrize("n,N,B", [(12, 128, 5), (12, 81, 3), (12, 100, 140), (12, 160, 2), (12, 161, 3), (12, 240, 70), (12, 320, 2),
                                    (12, 319, 1), (8, 129, 3), (8, 256, 70), (8, 300, 2), (8, 512, 1), (10, 97, 2), (10, 128, 140), (10, 200, 3),
-                                   (10, 384, 2), (16, 65, 2), (16, 128, 140), (16, 129, 3), (16, 200, 70), (16, 256, 2)])
+                                   (10, 384, 2), (16, 65, 2), (16, 128, 140), (16, 129, 3), (16, 200, 70), (16, 256, 2),
+                                   (18, 57, 2), (18, 112, 3), (18, 113, 2), (18, 128, 140), (18, 168, 70), (18, 224, 2)])
 def test_cluster_other_state_sizes(solver, orc, n, N, B):
-    """The same kernel at stateSize 8, 10, 12 and 16 (n / 2 lanes per knot, 128 / 96 / 80 / 64 knots per workgroup; at 16 the R
-    block of Pinv stays in LDS): two, three and four workgroups per problem, ragged splits, more problems
+    """The same kernel at stateSize 8, 10, 12, 16 and 18 (n / 2 lanes per knot, 128 / 96 / 80 / 64 / 56 knots per workgroup; at 16 the R
+    block of Pinv stays in LDS, at 18 its D block as well): two, three and four workgroups per problem, ragged splits, more problems
     than one round of clusters -- in general storage and, since symmetric STREAMING is slower than general RESIDENT, in the
     default symmetric mode as well."""
     base = min(B, 6)
@@ -139,11 +144,12 @@ def test_cluster_other_state_sizes(solver, orc, n, N, B):
                                          (10, np.float64, 49, 2), (10, np.float64, 128, 70), (10, np.float64, 192, 2), (8, np.float64, 65, 3),
                                          (8, np.float64, 200, 70), (8, np.float64, 256, 2), (9, np.float32, 57, 3), (9, np.float32, 128, 70),
                                          (9, np.float32, 224, 2), (11, np.float32, 41, 2), (11, np.float32, 128, 70), (11, np.float32, 160, 3),
-                                         (15, np.float32, 33, 3), (15, np.float32, 100, 70), (15, np.float32, 128, 5)])
+                                         (15, np.float32, 33, 3), (15, np.float32, 100, 70), (15, np.float32, 128, 5),
+                                         (16, np.float64, 33, 3), (16, np.float64, 100, 2), (16, np.float64, 128, 70)])
 def test_cluster_one_row_per_lane(solver, orc, n, dtype, N, B):
     """One row per lane: the BASELINE block size in fp64 (14 lanes per knot, 32 knots per workgroup, the
     hand-off words carry both halves of an fp64 value under their own tags) and stateSize 13 in fp32 (13 lanes per knot, direct
-    tile loads, one accumulator chain per row); the same template at stateSize 8, 10, 12 in fp64 and 9, 11, 15 in fp32.  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
+    tile loads, one accumulator chain per row); the same template at stateSize 8, 10, 12, 16 in fp64 (at 16 the D and R blocks of Pinv live in LDS) and 9, 11, 15 in fp32.  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
     the default symmetric mode (general RESIDENT beats symmetric STREAMING); then a fixed count from a warm start."""
     base = min(B, 6)
     d = synth.gen_numpy(n, N, seed=300 + N + n, batch=base, dtype=dtype)
@@ -164,6 +170,40 @@ def test_cluster_one_row_per_lane(solver, orc, n, dtype, N, B):
     ob = orc.pcg_batch(n, N, B, S, None, g, tol=0.0, max_iter=4, lambda0=lam0, nthreads=8)
     out = run(solver, n, N, B, S, None, g, lam0=lam0, tol=0.0, max_iter=4)
     check(out, ob, {"gamma": g}, B, ltol=20 * ltol, vtol=10 * vtol)
+
+
+@pytest.mark.parametrize("n,dtype,N", [(14, np.float32, 128), (16, np.float32, 128), (18, np.float32, 128), (12, np.float32, 100),
+                                       (14, np.float64, 64), (16, np.float64, 100), (13, np.float32, 100)])
+def test_cluster_matrices_aligned_to_8_bytes_only(solver, orc, n, dtype, N):
+    """Matrices that start 8 bytes past a 16-byte boundary: the coalesced LDS-DMA tile stages need 16-byte alignment, so the
+    kernel takes its direct tile loads (pcg_cluster_kernel<..., false>) -- at stateSize 16 / 18 and in fp64 the columns of Pinv
+    that live in LDS then go through the registers once per problem.  Same results as from aligned buffers."""
+    B = 3
+    es = np.dtype(dtype).itemsize
+    shift = 8 // es
+    d = synth.gen_numpy(n, N, seed=900 + n, batch=B, dtype=dtype)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    bufS = torch.zeros(d["S"].size + 4, dtype=tdt, device="cuda")
+    bufP = torch.zeros(d["Pinv"].size + 4, dtype=tdt, device="cuda")
+    assert bufS.data_ptr() % 16 == 0 and bufP.data_ptr() % 16 == 0
+    dS, dP = bufS[shift:shift + d["S"].size], bufP[shift:shift + d["Pinv"].size]
+    assert dS.data_ptr() % 16 == 8 and dP.data_ptr() % 16 == 8
+    dS.copy_(dev(d["S"]).reshape(-1))
+    dP.copy_(dev(d["Pinv"]).reshape(-1))
+    dg = dev(d["gamma"])
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    assert solver.cluster_members(es, n, N) >= 2
+    solver.set_symmetric(0)
+    try:
+        lam = torch.zeros_like(dg)
+        r, p = torch.full_like(dg, float("nan")), torch.full_like(dg, float("nan"))
+        it, fl = solver.solve(n, N, B, dS, dP, dg, lam, r, p, tol=1e-6, max_iter=100)
+        torch.cuda.synchronize()
+    finally:
+        solver.set_symmetric(2)
+    out = dict(lambda_=lam.cpu().numpy().reshape(B, -1), r=r.cpu().numpy().reshape(B, -1), p=p.cpu().numpy().reshape(B, -1),
+               iters=it.cpu().numpy().astype(np.int64), flag=fl.cpu().numpy().astype(np.int64))
+    check(out, ob, d, B, ltol=1e-10 if dtype == np.float64 else 1e-6, vtol=1e-9 if dtype == np.float64 else 2e-5)
 
 
 @pytest.mark.parametrize("N,B", [(250, 70), (150, 100), (288, 64), (100, 130)])
