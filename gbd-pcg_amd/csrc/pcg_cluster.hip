@@ -707,7 +707,14 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
     if (sizeof(T) == sizeof(TT) && n == NN) per_wg = DenseGeom<TT, NN, VV>::MAX_KNOTS;
     GBDPCG_CLUSTER_SHAPES(GBDPCG_X)
 #undef GBDPCG_X
-    if (per_wg == 0 || N <= per_wg) return 0;   // not built for the block size / pcg_resident.hip has it in one workgroup
+    if (per_wg == 0) return 0;                  // not built for the block size
+    // one workgroup holds the whole problem: pcg_resident.hip where it is built for the block size (its reductions stay in LDS); a
+    // "cluster" of one elsewhere (odd block sizes, 16 and 18, fp64 from 14 on) -- the kernel as it is, its one member polling its own
+    // partials (through LDS instead they would come 8 % sooner -- 114 vs 124 us per 1024 converged solves at 13 x 32 -- but the test
+    // for it inside the hand-off cost the clusters of two to four members 4 %: measured, taken out again)
+    if (N <= per_wg && resident_shape<T>(n, N)) return 0;
+    static const bool no_single = getenv("GBDPCG_NO_CLUSTER_OF_ONE") != nullptr;   // tuning runs
+    if (N <= per_wg && (no_single || N < 2)) return 0;
     const uint32_t H = (N + per_wg - 1) / per_wg;
     return H <= kClMaxH ? H : 0;
 }
@@ -726,7 +733,7 @@ size_t cluster_rescue_bytes(const DeviceInfo &dev)
     }
     GBDPCG_CLUSTER_SHAPES(GBDPCG_X)
 #undef GBDPCG_X
-    return (size_t)(dev.num_cus / 2) * bytes;
+    return (size_t)dev.num_cus * bytes;   // (a cluster may be a single workgroup)
 }
 
 template <typename T>
