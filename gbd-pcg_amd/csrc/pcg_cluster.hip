@@ -692,9 +692,11 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
 // stateSize 13 (odd: one fp32 row per lane, direct tile loads -- its blocks are not whole 16-byte pieces -- and one accumulator
 // chain per row).
 #define GBDPCG_CLUSTER_SHAPES(X) \
+    X(float, 3, 1) X(float, 5, 1) X(float, 7, 1) \
     X(float, 8, 2) X(float, 9, 1) X(float, 10, 2) X(float, 11, 1) X(float, 12, 2) X(float, 13, 1) X(float, 14, 2) X(float, 15, 1) X(float, 16, 2) \
     X(float, 18, 2) \
-    X(double, 8, 1) X(double, 10, 1) X(double, 12, 1) X(double, 14, 1) X(double, 16, 1)
+    X(double, 3, 1) X(double, 5, 1) X(double, 7, 1) X(double, 8, 1) X(double, 9, 1) X(double, 10, 1) X(double, 11, 1) X(double, 12, 1) \
+    X(double, 13, 1) X(double, 14, 1) X(double, 15, 1) X(double, 16, 1)
 
 // General storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n / V)) knots
 // -- 72 at n = 14 in fp32) up to kClMaxH times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).

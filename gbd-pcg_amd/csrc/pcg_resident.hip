@@ -15,7 +15,7 @@
 #define GBDPCG_RES_OCC 1   // 0: no register cap on the small-block instantiations of the resident kernel (A/B runs)
 #endif
 #if GBDPCG_RES_OCC
-#define GBDPCG_RES_OCC_ATTR __attribute__((amdgpu_waves_per_eu(NCT * sizeof(T) <= 32 || (NCT <= 6) ? 4 : 2)))   // n <= 8 in fp32, n <= 6 in fp64
+#define GBDPCG_RES_OCC_ATTR __attribute__((amdgpu_waves_per_eu(NCT * sizeof(T) <= 32 || (NCT <= 6) || (V == 1 && sizeof(T) == 4 && NCT <= 11) ? 4 : 2)))   // n <= 8 in fp32, n <= 6 in fp64, odd n <= 11 in fp32 (one row per lane: 6n matrix registers)
 #else
 #define GBDPCG_RES_OCC_ATTR
 #endif
@@ -186,16 +186,17 @@ __global__ __launch_bounds__(512) GBDPCG_RES_OCC_ATTR void pcg_resident_kernel(P
 // of N = 128.  Shorter problems of that block size stay with the streaming kernel: nothing is gained on 32 rows, and the
 // equal-iteration-count pin of the reference's example system (n = 2, N = 3, kappa ~ 1562, fp32: the count depends on the
 // summation order, and this kernel's order meets the exit test one iteration earlier) was taken with that kernel's order.
-#define GBDPCG_RESIDENT_N(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14)
+#define GBDPCG_RESIDENT_N(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+// rows per lane: two in fp32 where the block size is even (a lane's rows of a column are one 8-byte load), else one
+template <typename T, int NN> constexpr int resident_rows() { return sizeof(T) == 4 && NN % 2 == 0 ? 2 : 1; }
 constexpr uint32_t kResidentMinKnotsN2 = 16;
 
 template <typename T> bool resident_shape(uint32_t n, uint32_t N)
 {
     static const bool off = getenv("GBDPCG_NO_RESIDENT") != nullptr;
     if (off) return false;
-    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
 #define GBDPCG_X(NN) \
-    if (n == NN) return !(sizeof(T) == 8 && NN == 14) && !(NN == 2 && N < kResidentMinKnotsN2) && N <= DenseGeom<T, NN, RV>::MAX_KNOTS;
+    if (n == NN) return !(sizeof(T) == 8 && NN == 14) && !(NN == 2 && N < kResidentMinKnotsN2) && N <= DenseGeom<T, NN, resident_rows<T, NN>()>::MAX_KNOTS;
     GBDPCG_RESIDENT_N(GBDPCG_X)
 #undef GBDPCG_X
     return false;
@@ -214,7 +215,7 @@ template <typename K> static uint32_t resident_wgs_per_cu(K kern, uint32_t threa
 // (query = false: an unknown class then counts as 1; gbdpcg_graph_create_* asks before it starts the capture).
 template <typename T, int NN> static uint32_t resident_per_cu(size_t lds, bool query)
 {
-    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
+    constexpr int RV = resident_rows<T, NN>();
     static uint32_t per_cu[32] = {};
     const uint32_t cls = (uint32_t)(lds >> 13) < 31u ? (uint32_t)(lds >> 13) : 31u;
     uint32_t w = __atomic_load_n(&per_cu[cls], __ATOMIC_RELAXED);
@@ -228,7 +229,6 @@ template <typename T, int NN> static uint32_t resident_per_cu(size_t lds, bool q
 template <typename T> void resident_prepare(uint32_t n, uint32_t N)
 {
     if (!resident_shape<T>(n, N)) return;
-    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
     const size_t lds = ((size_t)2 * align16<T>((N + 2) * n) + 2 * align16<T>(8)) * sizeof(T);
 #define GBDPCG_X(NN)                                     \
     if constexpr (!(sizeof(T) == 8 && NN == 14)) {       \
@@ -236,13 +236,12 @@ template <typename T> void resident_prepare(uint32_t n, uint32_t N)
     }
     GBDPCG_RESIDENT_N(GBDPCG_X)
 #undef GBDPCG_X
-    (void)RV;
 }
 
 template <typename T, int NN>
 static bool launch_pcg_resident_n(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t s, hipError_t *err)
 {
-    constexpr int RV = sizeof(T) == 4 ? 2 : 1;
+    constexpr int RV = resident_rows<T, NN>();
     using Dg = DenseGeom<T, NN, RV>;
     static_assert(2 * Dg::REGS <= 176, "resident matrices must leave registers for the solve");
     const uintptr_t al = RV * sizeof(T);
