@@ -200,9 +200,10 @@ __device__ __forceinline__ void dense_mv(const DenseTile<T, NCT, V> &tl, const T
 // by the address path -- in pcg_cluster.hip 28 us of a 40 us round went there.
 template <typename T, int NCT, int V> struct DenseStage {
     using Dg = DenseGeom<T, NCT, V>;
-    static constexpr bool OK = V * sizeof(T) == 8 && (NCT * NCT * sizeof(T)) % 16 == 0;
     static constexpr uint32_t PIECES = NCT * NCT * sizeof(T) / 16;               // 16-byte pieces per n x n block
     static constexpr uint32_t LOADS = (Dg::BPW * PIECES + 63) / 64;              // LDS-DMA instructions per stage
+    // (the stages are written out for 4 .. 9 loads: block sizes below 8 take the direct loads)
+    static constexpr bool OK = V * sizeof(T) == 8 && (NCT * NCT * sizeof(T)) % 16 == 0 && LOADS >= 4 && LOADS <= 9;
     static constexpr uint32_t BYTES = LOADS * 64 * 16;                           // one staging buffer of one wave
     static constexpr uint32_t BLOCK_ROW_BYTES = 3 * NCT * NCT * sizeof(T);
 };

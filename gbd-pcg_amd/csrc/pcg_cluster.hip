@@ -692,10 +692,10 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
 // stateSize 13 (odd: one fp32 row per lane, direct tile loads -- its blocks are not whole 16-byte pieces -- and one accumulator
 // chain per row).
 #define GBDPCG_CLUSTER_SHAPES(X) \
-    X(float, 3, 1) X(float, 5, 1) X(float, 7, 1) \
+    X(float, 2, 2) X(float, 3, 1) X(float, 4, 2) X(float, 5, 1) X(float, 6, 2) X(float, 7, 1) \
     X(float, 8, 2) X(float, 9, 1) X(float, 10, 2) X(float, 11, 1) X(float, 12, 2) X(float, 13, 1) X(float, 14, 2) X(float, 15, 1) X(float, 16, 2) \
     X(float, 18, 2) \
-    X(double, 3, 1) X(double, 5, 1) X(double, 7, 1) X(double, 8, 1) X(double, 9, 1) X(double, 10, 1) X(double, 11, 1) X(double, 12, 1) \
+    X(double, 2, 1) X(double, 3, 1) X(double, 4, 1) X(double, 5, 1) X(double, 6, 1) X(double, 7, 1) X(double, 8, 1) X(double, 9, 1) X(double, 10, 1) X(double, 11, 1) X(double, 12, 1) \
     X(double, 13, 1) X(double, 14, 1) X(double, 15, 1) X(double, 16, 1)
 
 // General storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n / V)) knots
@@ -716,7 +716,8 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
     // for it inside the hand-off cost the clusters of two to four members 4 %: measured, taken out again)
     if (N <= per_wg && resident_shape<T>(n, N)) return 0;
     static const bool no_single = getenv("GBDPCG_NO_CLUSTER_OF_ONE") != nullptr;   // tuning runs
-    if (N <= per_wg && (no_single || N < 2)) return 0;
+    // (n = 2 below 16 knots stays with the streaming kernel, as in pcg_resident.hip: the reference's own example system lives there)
+    if (N <= per_wg && (no_single || N < 2 || (n == 2 && N < 16))) return 0;
     const uint32_t H = (N + per_wg - 1) / per_wg;
     return H <= kClMaxH ? H : 0;
 }

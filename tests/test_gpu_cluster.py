@@ -100,6 +100,9 @@ def test_cluster_shapes(solver):
     # stateSize 18: 9 lanes per knot, 56 knots per workgroup, the D and R blocks of Pinv in LDS
     assert solver.cluster_members(4, 18, 56) == 1 and solver.cluster_members(4, 18, 128) == 3 and solver.cluster_members(4, 18, 224) == 4
     assert solver.cluster_members(4, 18, 225) == 0 and solver.cluster_members(8, 18, 128) == 0 and solver.cluster_members(4, 20, 128) == 0
+    # the small blocks beyond pcg_resident.hip's horizons (512 / 256 / 168 knots in fp32); the reference's example system (2 x 3) streams
+    assert solver.cluster_members(4, 2, 512) == 0 and solver.cluster_members(4, 2, 513) == 2 and solver.cluster_members(4, 2, 3) == 0
+    assert solver.cluster_members(4, 4, 1024) == 4 and solver.cluster_members(4, 4, 1025) == 0 and solver.cluster_members(8, 6, 81) == 2
     # fp64 at stateSize 16: 16 lanes per knot, 32 knots per workgroup, the D and R blocks of Pinv in LDS
     assert solver.cluster_members(8, 16, 32) == 1 and solver.cluster_members(8, 16, 128) == 4 and solver.cluster_members(8, 16, 129) == 0
 
@@ -151,11 +154,15 @@ def test_cluster_other_state_sizes(solver, orc, n, N, B):
                                          (3, np.float32, 169, 3), (3, np.float32, 500, 70), (5, np.float32, 128, 70), (5, np.float32, 384, 2),
                                          (7, np.float32, 73, 3), (7, np.float32, 128, 70), (7, np.float32, 288, 2), (3, np.float64, 300, 5),
                                          (5, np.float64, 97, 70), (7, np.float64, 128, 5), (9, np.float64, 57, 3), (9, np.float64, 224, 2),
-                                         (11, np.float64, 128, 70), (13, np.float64, 33, 3), (13, np.float64, 128, 5), (15, np.float64, 128, 70)])
+                                         (11, np.float64, 128, 70), (13, np.float64, 33, 3), (13, np.float64, 128, 5), (15, np.float64, 128, 70),
+                                         (2, np.float32, 513, 3), (2, np.float32, 2048, 2), (2, np.float32, 700, 70), (4, np.float32, 257, 3),
+                                         (4, np.float32, 600, 70), (4, np.float32, 1024, 1), (6, np.float32, 169, 70), (6, np.float32, 672, 2),
+                                         (2, np.float64, 300, 70), (2, np.float64, 1024, 2), (4, np.float64, 129, 3), (4, np.float64, 512, 5),
+                                         (6, np.float64, 81, 70), (6, np.float64, 320, 2)])
 def test_cluster_one_row_per_lane(solver, orc, n, dtype, N, B):
     """One row per lane: the BASELINE block size in fp64 (14 lanes per knot, 32 knots per workgroup, the
     hand-off words carry both halves of an fp64 value under their own tags) and stateSize 13 in fp32 (13 lanes per knot, direct
-    tile loads, one accumulator chain per row); the same template at stateSize 8, 10, 12, 16 in fp64 (at 16 the D and R blocks of Pinv live in LDS), 9, 11, 15 in fp32, and at the small odd sizes (3, 5, 7; in fp64 every odd size up to 15).  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
+    tile loads, one accumulator chain per row); the same template at stateSize 8, 10, 12, 16 in fp64 (at 16 the D and R blocks of Pinv live in LDS), 9, 11, 15 in fp32, and at the small sizes (2 ... 7; in fp64 every odd size up to 15) for horizons beyond pcg_resident.hip's.  fp64 to 1e-10, fp32 to 1e-6, equal iteration counts; in general storage and in
     the default symmetric mode (general RESIDENT beats symmetric STREAMING); then a fixed count from a warm start."""
     base = min(B, 6)
     d = synth.gen_numpy(n, N, seed=300 + N + n, batch=base, dtype=dtype)
