@@ -152,11 +152,16 @@ __device__ __forceinline__ void load_unit(const T *__restrict__ Mk, uint32_t u, 
                                           StreamUnit<T, NCT, V> &t)
 {
     using Gm = StreamGeom<T, NCT, V>;
+    // The two offsets as values of their own: where the unit that holds the last step is only known at run time (n = 24 with
+    // V = 4: two units per row), hipcc turned the select between the two ADJACENT members into an indexed load, and with it the
+    // whole stream object -- the register ring included -- into scratch (552 bytes per lane, 2.8 TB/s instead of 5.6).
+    uint32_t o_lane = cx.off_lane, o_last = cx.off_last;
+    if (StreamCtx<T, NCT, V>::RAGGED) asm volatile("" : "+v"(o_last));
 #pragma unroll
     for (uint32_t j = 0; j < Gm::CH; ++j) {
         const uint32_t s = u * Gm::CH + j;
         if (Gm::STEPS % Gm::CH == 0 || s < Gm::STEPS) {
-            const uint32_t off = (StreamCtx<T, NCT, V>::RAGGED && s == Gm::STEPS - 1) ? cx.off_last : cx.off_lane;
+            const uint32_t off = (StreamCtx<T, NCT, V>::RAGGED && s == Gm::STEPS - 1) ? o_last : o_lane;
             VecIO<T, V>::template load<NT>(Mk + s * (Gm::G * Gm::N_) + off, t.a[j]);
         }
     }
