@@ -96,7 +96,7 @@ template <typename T> int choose_vec(uint32_t n, const void *const *ptrs, int np
 
 // Block sizes with a compile-time specialised kernel (everything else runs the runtime-n pipeline).
 // BASELINE shapes (14, 36), the reference's example (2) and common MPC state sizes.
-#define GBDPCG_SPECIALIZED_N(X) X(2) X(4) X(6) X(8) X(10) X(12) X(13) X(14) X(16) X(18) X(24) X(36)
+#define GBDPCG_SPECIALIZED_N(X) X(2) X(4) X(6) X(8) X(10) X(12) X(13) X(14) X(16) X(18) X(20) X(24) X(36)
 
 // Widest per-lane vector a specialised kernel of block size NCT is built with (the V choose_vec
 // returns for aligned pointers); other V values of that n fall back to the runtime-n kernel.

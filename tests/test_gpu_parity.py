@@ -178,7 +178,7 @@ def test_fp32_vs_oracle(solver, orc, golden_dir, path, n, N):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 16, 18, 20, 24, 36, 37, 48])
 def test_state_sizes(solver, orc, path, dtype, n):
-    """Every block size: the compile-time specialised kernels (2, 4, 6, 8, 12, 13, 14, 16, 18, 24, 36)
+    """Every block size: the compile-time specialised kernels (2, 4, 6, 8, 10, 12, 13, 14, 16, 18, 20, 24, 36)
     and the runtime-n pipeline (the rest) against the oracle, lambda and iteration count."""
     N, B = 11, 3
     d = synth.gen_numpy(n, N, seed=300 + n, batch=B, dtype=dtype)
