@@ -891,7 +891,7 @@ __global__ __launch_bounds__((K * PersistGeom<T, NCT>::TPK)) void pcg_persist1r_
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 
-#define GBDPCG_PERSIST_N(X) X(14) X(36)
+#define GBDPCG_PERSIST_N(X) X(14) X(16) X(18) X(20) X(24) X(36)
 
 template <typename T> static bool persist_has_kernel(uint32_t n)
 {

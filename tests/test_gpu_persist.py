@@ -190,7 +190,39 @@ def test_persistent_state_size_14(solver, orc, path, dtype, N, B):
         assert relerr(out["lambda_"][b], ob["lambda_"][b]) < (1e-10 if dtype == np.float64 else 1e-6)
 
 
+@pytest.mark.parametrize("path", [P, P1R], ids=["two-reductions", "one-reduction"])
+@pytest.mark.parametrize("n,dtype,N,B", [(16, np.float32, 300, 1), (16, np.float64, 256, 1), (16, np.float32, 33, 3), (18, np.float32, 256, 1),
+                                         (18, np.float64, 129, 2), (20, np.float32, 64, 1), (20, np.float32, 128, 2), (20, np.float64, 200, 1),
+                                         (24, np.float32, 128, 1), (24, np.float32, 400, 1), (24, np.float64, 256, 1), (24, np.float64, 3, 2)])
+def test_persistent_other_state_sizes(solver, orc, path, n, dtype, N, B):
+    """The persistent kernels at stateSize 16, 18, 20, 24 (round 3): one problem of 24 x 128 took 369 us on the split path -- a
+    graph of 2 max_iter + 4 launches whatever the iteration count -- and 60 us here.  Against the oracle to tolerance with equal
+    iteration counts, in both forms; then (the reference's recurrence) a fixed count from a warm start with r and p."""
+    d = synth.gen_numpy(n, N, seed=800 + N + n, batch=B, dtype=dtype)
+    tol = 1e-10 if dtype == np.float64 else 1e-6
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=100)
+    out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], path=path)
+    assert np.array_equal(out["iters"], ob["iters"].astype(np.int64)), (out["iters"], ob["iters"])
+    assert not out["flag"].any()
+    for b in range(B):
+        assert relerr(out["lambda_"][b], ob["lambda_"][b]) < tol
+    if path == P:
+        lam0 = (0.1 * np.random.default_rng(N).standard_normal((B, n * N))).astype(dtype)
+        ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=0.0, max_iter=5, lambda0=lam0)
+        out = run(solver, n, N, B, d["S"], d["Pinv"], d["gamma"], lam0=lam0, tol=0.0, max_iter=5, path=path)
+        assert (out["iters"] == 5).all() and (out["flag"] == 1).all()
+        for b in range(B):
+            assert relerr(out["lambda_"][b], ob["lambda_"][b]) < 2 * tol
+            scale = np.abs(d["gamma"][b]).max()
+            assert np.abs(out["r"][b] - ob["r"].reshape(B, -1)[b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
+            assert np.abs(out["p"][b] - ob["p"].reshape(B, -1)[b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
+
+
 def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
+    # block sizes beyond the on-chip kernels: one problem goes persistent instead of through 2 max_iter + 4 launches of the split path
+    assert solver.choose_path(4, 24, 128, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 20, 64, 1) == binding.PATH_PERSISTENT
+    assert solver.choose_path(4, 16, 300, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 16, 128, 1) == binding.PATH_FUSED
+    assert solver.choose_path(4, 22, 128, 1) == binding.PATH_SPLIT           # no persistent kernel of that size
     assert solver.choose_path(8, 14, 256, 1) == binding.PATH_PERSISTENT      # 2.4 MB per iteration through one CU otherwise
     # fp32: four CUs keep it resident on the cluster path (3.7 us per iteration against 4.7 here, tools/ab_cluster.py 256 1)
     assert solver.choose_path(4, 14, 256, 1) == binding.PATH_FUSED and solver.cluster_members(4, 14, 256) == 4
