@@ -1127,6 +1127,10 @@ template <typename T> uint32_t pinv_verdict_chunks(uint32_t n, uint32_t N, int k
     return specialised ? (N - 1 + 14) / 15 : 0;
 }
 
+// Block sizes with compile-time formation kernels: the streaming kernels' list plus the odd sizes and 22, which otherwise take the
+// runtime-n LDS kernels (stair of 1024 x 128 at n = 15: 1,093 us, at n = 22: 3,055 us).
+#define GBDPCG_PINV_N(X) GBDPCG_SPECIALIZED_N(X) X(3) X(5) X(7) X(9) X(11) X(15) X(22)
+
 template <typename T>
 hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint32_t batch, const T *S, T *Pinv,
                             int kind, hipStream_t s, uint8_t *verdicts, bool s_symmetric)
@@ -1184,7 +1188,7 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
             return hipGetLastError();                                                                                \
         }                                                                                                            \
     }
-    GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+    GBDPCG_PINV_N(GBDPCG_CASE)
 #undef GBDPCG_CASE
     // compile-time block sizes with one column per lane (32 < n <= 64): in-place elimination, one knot per wave;
     // the stair slots then come from the runtime-n LDS kernel
@@ -1206,7 +1210,7 @@ hipError_t launch_form_pinv(const DeviceInfo &dev, uint32_t n, uint32_t N, uint3
             }                                                                                                        \
         }                                                                                                            \
     }
-    GBDPCG_SPECIALIZED_N(GBDPCG_CASE)
+    GBDPCG_PINV_N(GBDPCG_CASE)
 #undef GBDPCG_CASE
     // wave-per-knot needs the whole [D|I] tableau to fit 16 elements per lane: 2 n^2 <= 1024
     // (EPT_MAX tableau elements per thread are held in registers across the read / write halves of a pivot step)

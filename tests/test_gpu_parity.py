@@ -388,7 +388,8 @@ def test_form_pinv(solver, dtype, kind, n):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n,N,B", [(14, 2, 2), (14, 15, 1), (14, 16, 3), (14, 17, 2), (14, 31, 1), (14, 128, 2),
                                    (8, 20, 2), (12, 33, 1), (16, 47, 2), (6, 5, 2), (13, 18, 1), (36, 4, 1), (36, 1, 2),
-                                   (36, 2, 1), (36, 21, 3)])
+                                   (36, 2, 1), (36, 21, 3), (3, 19, 3), (3, 2, 1), (5, 33, 2), (7, 18, 2), (9, 21, 1), (11, 17, 2), (15, 16, 2),
+                                   (15, 1, 1), (20, 9, 2), (22, 13, 2), (22, 2, 1), (24, 7, 1), (18, 10, 2), (10, 40, 1), (4, 64, 2), (2, 30, 3)])
 def test_form_pinv_shapes(solver, dtype, n, N, B):
     """The stair across the kernel families (fused 16-knot workgroups with their chunk seams at 15 / 16 / 17 knots,
     register Gauss-Jordan, LDS forms) against the host construction; exact symmetry wherever S is symmetric."""
