@@ -119,7 +119,10 @@ def main():
     for name, dstname, head in (("resident_stamps.txt", "resident_stamps.txt",
                                  "# gbd-pcg_amd/tools/rs_stamps.py (diagnostic build -DGBDPCG_RS_STAMPS: stamps in the loop, iterations ~20 % slower than shipped):\n"
                                  "# median over the 256 workgroups of the time between phase boundaries of each round, us (100 MHz real-time clock)\n"),
-                                ("solve_shapes.jsonl", "solve_shapes.jsonl", ""), ("ab_pinv.txt", "pinv_ab_latest.txt", "")):
+                                ("solve_shapes.jsonl", "solve_shapes.jsonl", ""), ("ab_pinv.txt", "pinv_ab_latest.txt", ""),
+                                ("pinv_shapes.txt", "pinv_shapes.txt", "# gbd-pcg_amd/tools/pinv_shapes.py: stair Phi^-1 formation by block size, 1024 problems x 128 knots\n"),
+                                ("spmv_shapes.txt", "spmv_shapes.txt", "# gbd-pcg_amd/tools/spmv_shapes.py: general-storage SpMV by block size, 1024 problems x 128 knots, >= 1.3 GB rotation\n"),
+                                ("single_problem.jsonl", "single_problem.jsonl", "")):
         sp = os.path.join(src, name)
         if os.path.exists(sp) and os.path.getsize(sp) > 0:
             body = "".join(ln for ln in open(sp) if "amdgpu.ids" not in ln)
