@@ -15,15 +15,15 @@ B="$ROOT/bench.py"
 echo "[1/6] bench line"
 python3 $B > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 echo "[2/6] kernel stats (config 3 only: the dispatches roofline.kernel_ms is measured on; then with the configs block)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B --no-cpu-baseline --no-configs > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B --no-cpu-baseline --no-configs --no-converged > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 $B --no-cpu-baseline > $OUT/stats_configs.log 2>&1 || { tail -5 $OUT/stats_configs.log; exit 1; }
 echo "[3/6] FETCH_SIZE"
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-converged > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
 echo "[4/6] WRITE_SIZE"
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-converged > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
 echo "[5/6] SQ counters"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
-    -d $OUT/sq -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/sq.log 2>&1 || { tail -5 $OUT/sq.log; exit 1; }
+    -d $OUT/sq -- python3 $B --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-converged > $OUT/sq.log 2>&1 || { tail -5 $OUT/sq.log; exit 1; }
 echo "[6/6] FETCH_SIZE calibration (bw_probe)"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/cal -- $ROOT/gbd-pcg_amd/tools/bw_probe > $OUT/bw_probe.txt 2> $OUT/cal.log || { tail -5 $OUT/cal.log; exit 1; }
 echo "[7] every single-GPU config, all paths (bench_configs.py)"
