@@ -279,8 +279,18 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
         // shapes the cluster kernel keeps resident in general storage gain nothing from symmetric STREAMING: only the
         // CU-resident symmetric kernel (N <= 128) is worth a symmetry test there
         const bool cluster_only = cluster_members<T>(n, N) != 0 && !resident_sym_shape<T>(n, N);
-        const bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && !cluster_only &&
-                             fused_has_symmetric<T>(h->dev, n, N, batch);
+        bool has_sym = h->symmetric != 0 && d_Pinv != nullptr && !cluster_only && fused_has_symmetric<T>(h->dev, n, N, batch);
+        // A batch that one round of clusters holds (stateSize 14, N <= 128: up to 128 problems) is not worth the test either: the
+        // cluster kernel solves it in general storage in one launch while the test, the symmetric launch and the general launch
+        // that finds nothing to do would still be starting (measured, 1 / 16 / 64 / 128 problems to 1e-6: 50 / 46 / 47 / 53 us
+        // against 52 / 61 / 65 / 74; from 160 problems on the two are level and the symmetric kernel then pulls away).
+        const uint32_t members = cluster_members<T>(n, N);
+        const bool one_cluster_round = members != 0 && (uint64_t)batch * members <= (uint64_t)h->dev.num_cus &&
+                                       !(reinterpret_cast<uintptr_t>(d_S) % 8) && !(d_Pinv && reinterpret_cast<uintptr_t>(d_Pinv) % 8);
+        // (in every form of mode 2 -- also where the verdicts are already known and the two paths are level --, so that
+        // gbdpcg_form_pinv_solve_* and gbdpcg_kkt_step_* stay bit-identical with the separate calls; mode 1, the caller's word, keeps
+        // the symmetric kernel)
+        if (h->symmetric == 2 && one_cluster_round) has_sym = false;
         if (has_sym && h->symmetric == 2 && known_symmetric) {
             // the caller inside this library KNOWS that every problem is symmetric in storage (gbdpcg_kkt_step_*: S written by
             // form_schur, Pinv by the stair kernel from that S): one launch, no test, no verdict bytes, no general launch

@@ -316,14 +316,18 @@ def test_cluster_identity_preconditioner(solver, orc):
 def test_cluster_takes_what_the_symmetry_test_rejects(solver, orc):
     """Default (tested) symmetric mode: storage that is symmetric goes to the CU-resident symmetric kernel, storage that
     is off by one ulp in one element goes to the cluster kernel -- in one call, each problem equal to the oracle run on the
-    very matrices it was given."""
-    n, N, B = 14, 128, 24
-    d = synth.gen_numpy(n, N, seed=611, batch=B, dtype=np.float32)
-    S = unsymmetrize(d["S"], n, N, B, every=3)
-    Pinv = unsymmetrize(d["Pinv"], n, N, B, every=4)
-    ob = orc.pcg_batch(n, N, B, S, Pinv, d["gamma"], tol=1e-6, max_iter=100)
-    out = run(solver, n, N, B, S, Pinv, d["gamma"], symmetric=2)
-    check(out, ob, d, B)
+    very matrices it was given.  (140 problems: a batch one round of clusters holds -- 128 here -- goes to the cluster kernel as a
+    whole, without the test; checked with 24 problems as well.)"""
+    n, N = 14, 128
+    for B in (140, 24):
+        d0 = synth.gen_numpy(n, N, seed=611, batch=24, dtype=np.float32)
+        idx = np.arange(B) % 24
+        d = {"S": d0["S"][idx], "Pinv": d0["Pinv"][idx], "gamma": (d0["gamma"][idx] * (1.0 + 0.01 * (np.arange(B) // 24))[:, None]).astype(np.float32)}
+        S = unsymmetrize(d["S"], n, N, B, every=3)
+        Pinv = unsymmetrize(d["Pinv"], n, N, B, every=4)
+        ob = orc.pcg_batch(n, N, B, S, Pinv, d["gamma"], tol=1e-6, max_iter=100, nthreads=8)
+        out = run(solver, n, N, B, S, Pinv, d["gamma"], symmetric=2)
+        check(out, ob, d, B)
 
 
 @pytest.mark.parametrize("tol,max_iter", [(1e-6, 0), (1e-6, 1), (1e30, 5), (0.0, 2), (0.0, 7)])
