@@ -291,7 +291,8 @@ def test_persistent_launch_gives_up_instead_of_hanging(form):
     assert _hooked(form, 36, 64, "f64", GBDPCG_PERSIST_DROP_WG="1", GBDPCG_PERSIST_SPIN_LIMIT="2000", GBDPCG_RESCUE_OFF="1") == "seen"
 
 
-@pytest.mark.parametrize("form,n,N,dt", [("2r", 36, 64, "f64"), ("1r", 36, 64, "f64"), ("2r", 14, 200, "f32"), ("2r", 36, 256, "f64")])
+@pytest.mark.parametrize("form,n,N,dt", [("2r", 36, 64, "f64"), ("1r", 36, 64, "f64"), ("2r", 14, 200, "f32"), ("2r", 36, 256, "f64"),
+                                        ("2r", 24, 64, "f32"), ("1r", 20, 100, "f64")])
 def test_persistent_give_up_is_rescued(form, n, N, dt):
     """The same fault with the library's default behaviour: the streaming launch queued behind the persistent one solves
     the marked problem from the untouched inputs -- vectors in LDS where one workgroup holds them (n = 14, N = 200), in
