@@ -152,6 +152,11 @@ template <typename T> size_t persist_rescue_bytes(uint32_t n, uint32_t N, uint32
 template <typename T>
 hipError_t launch_pcg_persist(const DeviceInfo &dev, const PcgArgs<T> &a, void *workspace, hipStream_t s,
                               bool one_reduction = false);   // one_reduction: the Chronopoulos-Gear form (opt-in path 4)
+// (the kernels of the block sizes 22 - 28 / 30 - 36, compiled in units of their own: pcg_persist_b.hip / pcg_persist_c.hip)
+template <typename T>
+hipError_t launch_pcg_persist_b(const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction, uint32_t K);
+template <typename T>
+hipError_t launch_pcg_persist_c(const PcgArgs<T> &a, void *workspace, hipStream_t s, bool one_reduction, uint32_t K);
 
 // ---- symcheck.hip : flags[b] = 1 iff L_{k+1} == R_k^T bit for bit for every k of problem b
 // and_into: flags[b] &= result instead of flags[b] = result (second matrix of a pair).

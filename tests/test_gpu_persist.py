@@ -193,9 +193,11 @@ def test_persistent_state_size_14(solver, orc, path, dtype, N, B):
 @pytest.mark.parametrize("path", [P, P1R], ids=["two-reductions", "one-reduction"])
 @pytest.mark.parametrize("n,dtype,N,B", [(16, np.float32, 300, 1), (16, np.float64, 256, 1), (16, np.float32, 33, 3), (18, np.float32, 256, 1),
                                          (18, np.float64, 129, 2), (20, np.float32, 64, 1), (20, np.float32, 128, 2), (20, np.float64, 200, 1),
-                                         (24, np.float32, 128, 1), (24, np.float32, 400, 1), (24, np.float64, 256, 1), (24, np.float64, 3, 2)])
+                                         (24, np.float32, 128, 1), (24, np.float32, 400, 1), (24, np.float64, 256, 1), (24, np.float64, 3, 2),
+                                         (22, np.float32, 128, 1), (26, np.float32, 100, 1), (28, np.float64, 64, 1), (30, np.float32, 200, 1),
+                                         (32, np.float32, 256, 1), (32, np.float64, 33, 2), (34, np.float32, 128, 1)])
 def test_persistent_other_state_sizes(solver, orc, path, n, dtype, N, B):
-    """The persistent kernels at stateSize 16, 18, 20, 24 (round 3): one problem of 24 x 128 took 369 us on the split path -- a
+    """The persistent kernels at the even block sizes between BASELINE's 14 and 36 (round 3): one problem of 24 x 128 took 369 us on the split path -- a
     graph of 2 max_iter + 4 launches whatever the iteration count -- and 60 us here.  Against the oracle to tolerance with equal
     iteration counts, in both forms; then (the reference's recurrence) a fixed count from a warm start with r and p."""
     d = synth.gen_numpy(n, N, seed=800 + N + n, batch=B, dtype=dtype)
@@ -222,7 +224,8 @@ def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
     # block sizes beyond the on-chip kernels: one problem goes persistent instead of through 2 max_iter + 4 launches of the split path
     assert solver.choose_path(4, 24, 128, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 20, 64, 1) == binding.PATH_PERSISTENT
     assert solver.choose_path(4, 16, 300, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 16, 128, 1) == binding.PATH_FUSED
-    assert solver.choose_path(4, 22, 128, 1) == binding.PATH_SPLIT           # no persistent kernel of that size
+    assert solver.choose_path(4, 22, 128, 1) == binding.PATH_PERSISTENT and solver.choose_path(8, 32, 64, 1) == binding.PATH_PERSISTENT
+    assert solver.choose_path(4, 38, 128, 1) == binding.PATH_SPLIT           # no persistent kernel of that size
     assert solver.choose_path(8, 14, 256, 1) == binding.PATH_PERSISTENT      # 2.4 MB per iteration through one CU otherwise
     # fp32: four CUs keep it resident on the cluster path (3.7 us per iteration against 4.7 here, tools/ab_cluster.py 256 1)
     assert solver.choose_path(4, 14, 256, 1) == binding.PATH_FUSED and solver.cluster_members(4, 14, 256) == 4
