@@ -286,6 +286,7 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
         // against 52 / 61 / 65 / 74; from 160 problems on the two are level and the symmetric kernel then pulls away).
         const uint32_t members = cluster_members<T>(n, N);
         const bool one_cluster_round = members != 0 && (uint64_t)batch * members <= (uint64_t)h->dev.num_cus &&
+                                       max_iter < (1u << 18) &&   // (its hand-off tags count 2 max_iter + 4 epochs per problem in 20 bits)
                                        !(reinterpret_cast<uintptr_t>(d_S) % 8) && !(d_Pinv && reinterpret_cast<uintptr_t>(d_Pinv) % 8);
         // (in every form of mode 2 -- also where the verdicts are already known and the two paths are level --, so that
         // gbdpcg_form_pinv_solve_* and gbdpcg_kkt_step_* stay bit-identical with the separate calls; mode 1, the caller's word, keeps
