@@ -246,6 +246,23 @@ template <typename T> size_t persist_total_bytes(gbdpcg_handle_t, uint32_t n, ui
     return persist_rescue_offset<T>(n, N, batch) + persist_rescue_bytes<T>(n, N, batch);
 }
 
+// A few problems too many for ONE persistent launch (stateSize 20 ... 36 beyond the on-chip kernels: one or two, at short horizons
+// four or five, per launch) used to fall to the split path, whose hipGraph is 2 max_iter + 4 launches whatever the iteration count
+// (8 problems of 24 x 128 under max_iter = 100: 370 us of launches for nine iterations).  They are solved by a few persistent
+// launches in a row instead, `persist_slices` problems each, when that row is shorter than the split path's launches alone:
+// 25 us of fixed cost per persistent launch against 1.8 us per launch of the split graph.  0: no slicing.
+template <typename T> uint32_t persist_slices(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t batch, uint32_t max_iter)
+{
+    static const bool off = getenv("GBDPCG_NO_PERSIST_SLICES") != nullptr;   // tuning runs only
+    if (off || h->forced != GBDPCG_PATH_AUTO || pick_path<T>(h, n, N, batch) != GBDPCG_PATH_SPLIT) return 0;
+    uint32_t cap = 0;
+    for (uint32_t b = 1; b <= 64 && b < batch && persist_knots_per_wg<T>(h->dev, n, N, b) != 0; ++b) cap = b;
+    if (cap == 0) return 0;
+    const uint32_t launches = (batch + cap - 1) / cap;
+    if (launches > 16 || 25.0 * launches >= 1.8 * (2.0 * max_iter + 4.0)) return 0;
+    return cap;
+}
+
 gbdpcg_status ensure_sym_flags(gbdpcg_handle_t h, size_t batch)
 {
     return grow_buffer(h, reinterpret_cast<void **>(&h->sym_flags), &h->sym_cap, batch);
@@ -263,6 +280,17 @@ gbdpcg_status solve_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint32_t bat
     a.cluster_ws = h->cluster_ws;
     a.rescue_vec = h->cluster_rescue;   // (the persistent path points it at its own buffer below)
     DEVICE_SCOPE(h);
+    if (const uint32_t per = persist_slices<T>(h, n, N, batch, max_iter)) {
+        const size_t ms = (size_t)3 * n * n * N, vs = (size_t)n * N;
+        for (uint32_t b0 = 0; b0 < batch; b0 += per) {
+            const uint32_t nb = batch - b0 < per ? batch - b0 : per;
+            const gbdpcg_status st = solve_impl<T>(h, n, N, nb, d_S + b0 * ms, d_Pinv ? d_Pinv + b0 * ms : nullptr, d_gamma + b0 * vs,
+                                                   d_lambda + b0 * vs, d_r ? d_r + b0 * vs : nullptr, d_p ? d_p + b0 * vs : nullptr, tol,
+                                                   max_iter, d_iters + b0, d_exit ? d_exit + b0 : nullptr, stream);
+            if (st != GBDPCG_OK) return st;
+        }
+        return GBDPCG_OK;
+    }
     const gbdpcg_path path = pick_path<T>(h, n, N, batch);
     if (path == GBDPCG_PATH_PERSISTENT || path == GBDPCG_PATH_PERSISTENT_1R) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -540,7 +568,12 @@ gbdpcg_status graph_create_impl(gbdpcg_handle_t h, uint32_t n, uint32_t N, uint3
     *out = nullptr;
     if (!shape_ok(n, N, batch)) return GBDPCG_ERR_INVALID;
     DEVICE_SCOPE(h);
-    if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT || pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT_1R) {
+    if (const uint32_t per = persist_slices<T>(h, n, N, batch, max_iter)) {   // the hand-off words of the slices (solve_impl)
+        void *pws = nullptr;
+        gbdpcg_status st = get_pws(h, sizeof(T), n, N, per, persist_total_bytes<T>(h, n, N, per), true, &pws);
+        if (st == GBDPCG_OK && batch % per) st = get_pws(h, sizeof(T), n, N, batch % per, persist_total_bytes<T>(h, n, N, batch % per), true, &pws);
+        if (st != GBDPCG_OK) return st;
+    } else if (pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT || pick_path<T>(h, n, N, batch) == GBDPCG_PATH_PERSISTENT_1R) {
         void *pws = nullptr;
         gbdpcg_status st = get_pws(h, sizeof(T), n, N, batch, persist_total_bytes<T>(h, n, N, batch), true, &pws);
         if (st != GBDPCG_OK) return st;
@@ -831,6 +864,17 @@ gbdpcg_status gbdpcg_reserve(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, 
     if (p == GBDPCG_PATH_PERSISTENT || p == GBDPCG_PATH_PERSISTENT_1R) {
         void *pws = nullptr;
         return get_pws(h, elem_size, n, N, batch, gbdpcg_workspace_bytes(h, elem_size, n, N, batch), true, &pws);
+    }
+    // a batch that a later solve may cut into persistent launches (persist_slices: whether it does depends on that call's max_iter):
+    // the slices' hand-off words as well as the split path's workspace
+    const uint32_t per = elem_size == 8 ? persist_slices<double>(h, n, N, batch, 0x7fffffffu) : persist_slices<float>(h, n, N, batch, 0x7fffffffu);
+    if (per) {
+        void *pws = nullptr;
+        for (uint32_t nb : {per, batch % per}) {
+            if (nb == 0) continue;
+            st = get_pws(h, elem_size, n, N, nb, elem_size == 8 ? persist_total_bytes<double>(h, n, N, nb) : persist_total_bytes<float>(h, n, N, nb), true, &pws);
+            if (st != GBDPCG_OK) return st;
+        }
     }
     return ensure_ws(h, gbdpcg_workspace_bytes(h, elem_size, n, N, batch));
 }

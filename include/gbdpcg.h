@@ -100,7 +100,9 @@ const char *gbdpcg_last_hip_error_string(gbdpcg_handle_t h);
 
 /* Force a path for subsequent solves on this handle (tests / benchmarks). */
 gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path);
-/* Path AUTO would take for this shape (elem_size 4 or 8). */
+/* Path AUTO would take for this shape (elem_size 4 or 8).  One refinement is decided per solve, where max_iter is known: a
+ * batch reported as GBDPCG_PATH_SPLIT that exceeds ONE persistent launch by a few problems (stateSize 14 ... 36) is cut into
+ * persistent launches in a row when those cost less than the split path's 2 max_iter + 4 launches. */
 gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
                                uint32_t batch);
 /* Compute units a GENERAL-storage problem of this shape is spread over inside the fused path (pcg_cluster.hip: both

@@ -220,6 +220,45 @@ def test_persistent_other_state_sizes(solver, orc, path, n, dtype, N, B):
             assert np.abs(out["p"][b] - ob["p"].reshape(B, -1)[b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
 
 
+@pytest.mark.parametrize("n,dtype,N,B,max_iter", [(36, np.float64, 256, 3, 100), (36, np.float64, 256, 8, 100), (24, np.float32, 128, 8, 100),
+                                                  (24, np.float32, 128, 11, 60), (20, np.float64, 200, 5, 100), (32, np.float32, 100, 9, 200),
+                                                  (24, np.float32, 128, 8, 12)])
+def test_small_batches_of_large_problems_go_persistent_in_slices(solver, orc, n, dtype, N, B, max_iter):
+    """A few problems more than one persistent launch holds: AUTO cuts the batch into persistent launches in a row (api.hip,
+    persist_slices) instead of the split path's 2 max_iter + 4 launches -- unless max_iter is so small that the split graph is the
+    shorter one (last case).  Every problem against the oracle, warm start, r and p included; then the same as a hipGraph."""
+    es = np.dtype(dtype).itemsize
+    assert solver.choose_path(es, n, N, B) == binding.PATH_SPLIT and solver.choose_path(es, n, N, 1) == binding.PATH_PERSISTENT
+    d = synth.gen_numpy(n, N, seed=1500 + n + B, batch=B, dtype=dtype)
+    tol = 1e-10 if dtype == np.float64 else 1e-6
+    lam0 = (0.05 * np.random.default_rng(B).standard_normal((B, n * N))).astype(dtype)
+    ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=max_iter, lambda0=lam0, nthreads=8)
+    dS, dP, dg = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+    lam = dev(lam0)
+    r, p = torch.full_like(dg, float("nan")), torch.full_like(dg, float("nan"))
+    it, fl = solver.solve(n, N, B, dS, dP, dg, lam, r, p, tol=1e-6, max_iter=max_iter)
+    torch.cuda.synchronize()
+    assert np.array_equal(it.cpu().numpy().astype(np.int64), ob["iters"].astype(np.int64))
+    assert np.array_equal(fl.cpu().numpy().astype(bool), ob["max_iter_exit"].astype(bool))
+    lam_h, r_h, p_h = (x.cpu().numpy().reshape(B, -1) for x in (lam, r, p))
+    for b in range(B):
+        assert relerr(lam_h[b], ob["lambda_"][b]) < tol, b
+        scale = np.abs(d["gamma"][b]).max()
+        assert np.abs(r_h[b] - ob["r"].reshape(B, -1)[b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
+        assert np.abs(p_h[b] - ob["p"].reshape(B, -1)[b]).max() < (1e-9 if dtype == np.float64 else 2e-5) * scale
+    # captured: the slices' hand-off words are reserved by the graph entry point before the capture starts
+    lam2 = dev(lam0)
+    it2 = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fl2 = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    g = solver.graph_solve(n, N, B, dS, dP, dg, lam2, None, None, 1e-6, max_iter, it2, fl2)
+    for _ in range(2):
+        lam2.copy_(dev(lam0))
+        g.launch()
+    torch.cuda.synchronize()
+    g.close()
+    assert torch.equal(lam2, lam) and np.array_equal(it2.cpu().numpy(), it.cpu().numpy().astype(np.int32))
+
+
 def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
     # block sizes beyond the on-chip kernels: one problem goes persistent instead of through 2 max_iter + 4 launches of the split path
     assert solver.choose_path(4, 24, 128, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 20, 64, 1) == binding.PATH_PERSISTENT
