@@ -950,7 +950,8 @@ static uint32_t waves_for(const DeviceInfo &dev, size_t wave_bytes)
 // The block sizes the four-knots-per-wave kernels are built for: stateSize = 2 x joints, controlSize = joints (a manipulator's
 // positions and velocities against its torques; 14 / 7 is the BASELINE shape), and the pendulum (2 / 1), cart-pole (4 / 1) and
 // quadrotor (12 / 4, 13 / 4 with a quaternion) shapes of the MPC literature.  Other sizes take the any-size LDS kernels.
-#define GBDPCG_QUAD_SHAPES(X) X(2, 1) X(4, 1) X(4, 2) X(6, 3) X(8, 4) X(10, 5) X(12, 4) X(12, 6) X(13, 4) X(14, 7)
+#define GBDPCG_QUAD_SHAPES(X) X(2, 1) X(4, 1) X(4, 2) X(6, 3) X(8, 4) X(10, 5) X(12, 4) X(12, 6) X(13, 4) X(14, 7) \
+    X(3, 1) X(5, 2) X(6, 1) X(6, 2) X(7, 3) X(8, 2) X(9, 3) X(10, 4) X(11, 4) X(12, 3)   /* round 3: under-actuated and odd shapes (9 / 3, 1024 x 128: formation 512 -> 95 us, recovery 95 -> 30 us) */
 
 template <typename T, int NX, int NU>
 hipError_t launch_form_quad(const DeviceInfo &dev, uint32_t N, uint32_t batch, const T *G, const T *C, const T *g, const T *c, T *S,

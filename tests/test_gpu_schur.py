@@ -102,7 +102,8 @@ def test_four_knot_form_runs_of_every_length(solver, N, B):
         test_form_schur_and_recover_vs_oracle(solver, 14, 7, N, B, dtype, tol)
 
 
-QUAD_SHAPES = [(2, 1), (4, 1), (4, 2), (6, 3), (8, 4), (10, 5), (12, 4), (12, 6), (13, 4), (14, 7)]   # GBDPCG_QUAD_SHAPES of csrc/schur.hip
+QUAD_SHAPES = [(2, 1), (4, 1), (4, 2), (6, 3), (8, 4), (10, 5), (12, 4), (12, 6), (13, 4), (3, 1), (5, 2), (6, 1), (6, 2), (7, 3), (8, 2), (9, 3),
+               (10, 4), (11, 4), (12, 3), (14, 7)]   # GBDPCG_QUAD_SHAPES of csrc/schur.hip (14 / 7 last: it has tests of its own)
 
 
 @pytest.mark.parametrize("nx,nu", QUAD_SHAPES[:-1])
