@@ -116,8 +116,17 @@ template <typename T, int NCT, int V, bool STAGED> struct ClusterTailBytes {
 
 }  // namespace
 
+// Instantiations light enough for two workgroups to share a compute unit (launch_pcg_cluster): held to 128 registers.  fp32 at
+// stateSize 2, 3, 4, 5, 7, 9, 11 need 108-118 anyway; 6 (144), 13 (132) and fp64 at 2-5 (139) are asked to fit (2-12 registers
+// spilled, and still 1.3-1.6x faster with two per CU: 1024 converged solves of 9 x 128: 516 -> 317 us, 13 x 128: 491 -> 367,
+// 6 x 200: 212 -> 151, fp64 4 x 200: 208 -> 134).  Not stateSize 15: it also runs as a cluster of ONE, one per CU, where the
+// 20 registers the cap spills cost 30 %.
+template <typename T, int NCT> struct ClusterLight {
+    static constexpr bool value = (sizeof(T) == 4 && (NCT <= 7 || NCT == 9 || NCT == 11 || NCT == 13)) || (sizeof(T) == 8 && NCT <= 5);
+};
 template <typename T, int NCT, int V, bool STAGED>
-__global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(ClusterLight<T, NCT>::value ? 4 : 2)))
+void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
                                                           uint32_t clusters, uint32_t spin_limit, uint32_t drop_block, bool no_plain)
 {
 #ifndef GBDPCG_TEST_HOOKS
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(512) void pcg_cluster_kernel(PcgArgs<T> a, unsigned
     if (blk == 0 && wave == (WAVE) && lane == 0 && (COND)) reinterpret_cast<u64 *>(ws)[IDX] = __builtin_amdgcn_s_memrealtime();
 // start (0) / end (1) of every workgroup, behind the slots as sized for the device (256 CUs on the MI355X)
 #define GBDPCG_CL_STAMP_WG(WHICH)                                                                                    \
-    if (tid == 0) reinterpret_cast<u64 *>(ws + kClCtrlBytes + 2u * 256u * kClSlotBytes)[2 * blk + (WHICH)] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) reinterpret_cast<u64 *>(ws + kClCtrlBytes + 2u * 512u * kClSlotBytes)[2 * blk + (WHICH)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GBDPCG_CL_STAMP_WG(WHICH)
 #define GBDPCG_CL_STAMP(IDX, WAVE, COND)
@@ -723,7 +732,8 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
 }
 
 // ... plus 16 bytes per CU behind the slots: start / end of every workgroup on the real-time clock (diagnostic build only)
-size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (size_t)2 * dev.num_cus * kClSlotBytes + (size_t)dev.num_cus * 16; }
+// (slots for two workgroups per CU: the light instantiations run two -- cluster_wgs_per_cu)
+size_t cluster_workspace_bytes(const DeviceInfo &dev) { return kClCtrlBytes + (size_t)2 * (2 * dev.num_cus) * kClSlotBytes + (size_t)(2 * dev.num_cus) * 16; }
 
 // Device memory for the in-kernel rescue: one set of vectors per cluster, sized for the longest horizon the path takes.
 size_t cluster_rescue_bytes(const DeviceInfo &dev)
@@ -745,7 +755,17 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
     const uint32_t H = cluster_members<T>(a.n, a.N);
     if (H == 0 || !a.cluster_ws || a.symmetric) return false;
     if ((reinterpret_cast<uintptr_t>(a.S) % 8) || (a.Pinv && reinterpret_cast<uintptr_t>(a.Pinv) % 8)) return false;
-    uint32_t clusters = (uint32_t)dev.num_cus / H;   // one workgroup per CU: a cluster's members are resident together
+    // one workgroup per CU: a cluster's members are resident together -- two where the instantiation is light enough for two to
+    // share a CU (ClusterLight: at most 128 VGPRs, no dynamic LDS, and always two or more members, pcg_resident.hip having the
+    // short horizons: so never more than CU-count clusters, which is what the control words hold)
+    static const int per_cu_env = [] { const char *e = getenv("GBDPCG_CLUSTER_PER_CU"); return e ? atoi(e) : 0; }();   // tuning runs
+    bool light = false;
+#define GBDPCG_X(TT, NN, VV) \
+    if (sizeof(T) == sizeof(TT) && a.n == NN) light = ClusterLight<TT, NN>::value && H >= 2;
+    GBDPCG_CLUSTER_SHAPES(GBDPCG_X)
+#undef GBDPCG_X
+    const uint32_t per_cu = light ? (per_cu_env ? (uint32_t)per_cu_env : 2u) : 1u;
+    uint32_t clusters = (uint32_t)dev.num_cus * (per_cu > 2 ? 2u : per_cu) / H;
     if (clusters > a.batch) clusters = a.batch;
     if (clusters == 0) return false;
     const uint32_t rounds = (a.batch + clusters - 1) / clusters;

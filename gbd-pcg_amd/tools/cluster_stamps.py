@@ -47,7 +47,7 @@ for rep in range(10):
 # every workgroup's start and end on the real-time clock (last solve)
 wg = (ctypes.c_uint64 * 512)()
 # kClCtrlBytes + two parities of 640-byte slots (pcg_cluster.hip)
-assert hip.hipMemcpy(wg, ctypes.c_void_p(fn(s.h) + (256 + 256 * 16) + 2 * 256 * 640), 4096, 2) == 0
+assert hip.hipMemcpy(wg, ctypes.c_void_p(fn(s.h) + (256 + 256 * 16) + 2 * 512 * 640), 4096, 2) == 0
 nb = min(256, 2 * min(B, 128))
 st = [wg[2 * i] for i in range(nb)]
 en = [wg[2 * i + 1] for i in range(nb)]
