@@ -119,10 +119,10 @@ template <typename T, int NCT, int V, bool STAGED> struct ClusterTailBytes {
 // Instantiations light enough for two workgroups to share a compute unit (launch_pcg_cluster): held to 128 registers.  fp32 at
 // stateSize 2, 3, 4, 5, 7, 9, 11 need 108-118 anyway; 6 (144), 13 (132) and fp64 at 2-5 (139) are asked to fit (2-12 registers
 // spilled, and still 1.3-1.6x faster with two per CU: 1024 converged solves of 9 x 128: 516 -> 317 us, 13 x 128: 491 -> 367,
-// 6 x 200: 212 -> 151, fp64 4 x 200: 208 -> 134).  Not stateSize 15: it also runs as a cluster of ONE, one per CU, where the
-// 20 registers the cap spills cost 30 %.
+// 6 x 200: 212 -> 151, fp64 4 x 200: 208 -> 134).  stateSize 15 (143: 20 spilled) gains 14 % that way (531 -> 455 us) and never runs as
+// a cluster of one, where the cap alone would cost 30 %: pcg_resident.hip has its short horizons.
 template <typename T, int NCT> struct ClusterLight {
-    static constexpr bool value = (sizeof(T) == 4 && (NCT <= 7 || NCT == 9 || NCT == 11 || NCT == 13)) || (sizeof(T) == 8 && NCT <= 5);
+    static constexpr bool value = (sizeof(T) == 4 && (NCT <= 7 || NCT == 9 || NCT == 11 || NCT == 13 || NCT == 15)) || (sizeof(T) == 8 && NCT <= 5);
 };
 template <typename T, int NCT, int V, bool STAGED>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(ClusterLight<T, NCT>::value ? 4 : 2)))

@@ -186,9 +186,15 @@ __global__ __launch_bounds__(512) GBDPCG_RES_OCC_ATTR void pcg_resident_kernel(P
 // of N = 128.  Shorter problems of that block size stay with the streaming kernel: nothing is gained on 32 rows, and the
 // equal-iteration-count pin of the reference's example system (n = 2, N = 3, kappa ~ 1562, fp32: the count depends on the
 // summation order, and this kernel's order meets the exit test one iteration earlier) was taken with that kernel's order.
-#define GBDPCG_RESIDENT_N(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+#define GBDPCG_RESIDENT_N(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 // rows per lane: two in fp32 where the block size is even (a lane's rows of a column are one 8-byte load), else one
 template <typename T, int NN> constexpr int resident_rows() { return sizeof(T) == 4 && NN % 2 == 0 ? 2 : 1; }
+// ... and whether the kernel is built for the pair at all: both tiles must leave registers for the solve (fp64 at 14 and 15: 168 / 180
+// matrix registers plus the fp64 working set spill -- the cluster kernel has those, with part of Pinv in LDS)
+template <typename T, int NN> constexpr bool resident_built()
+{
+    return 2 * DenseGeom<T, NN, resident_rows<T, NN>()>::REGS <= 176 && !(sizeof(T) == 8 && NN == 14);
+}
 constexpr uint32_t kResidentMinKnotsN2 = 16;
 
 template <typename T> bool resident_shape(uint32_t n, uint32_t N)
@@ -196,7 +202,7 @@ template <typename T> bool resident_shape(uint32_t n, uint32_t N)
     static const bool off = getenv("GBDPCG_NO_RESIDENT") != nullptr;
     if (off) return false;
 #define GBDPCG_X(NN) \
-    if (n == NN) return !(sizeof(T) == 8 && NN == 14) && !(NN == 2 && N < kResidentMinKnotsN2) && N <= DenseGeom<T, NN, resident_rows<T, NN>()>::MAX_KNOTS;
+    if (n == NN) return resident_built<T, NN>() && !(NN == 2 && N < kResidentMinKnotsN2) && N <= DenseGeom<T, NN, resident_rows<T, NN>()>::MAX_KNOTS;
     GBDPCG_RESIDENT_N(GBDPCG_X)
 #undef GBDPCG_X
     return false;
@@ -231,7 +237,7 @@ template <typename T> void resident_prepare(uint32_t n, uint32_t N)
     if (!resident_shape<T>(n, N)) return;
     const size_t lds = ((size_t)2 * align16<T>((N + 2) * n) + 2 * align16<T>(8)) * sizeof(T);
 #define GBDPCG_X(NN)                                     \
-    if constexpr (!(sizeof(T) == 8 && NN == 14)) {       \
+    if constexpr (resident_built<T, NN>()) {             \
         if (n == NN) (void)resident_per_cu<T, NN>(lds, true); \
     }
     GBDPCG_RESIDENT_N(GBDPCG_X)
@@ -283,7 +289,7 @@ bool launch_pcg_resident(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t
 {
     if (!resident_shape<T>(a.n, a.N)) return false;
 #define GBDPCG_X(NN)                                                        \
-    if constexpr (!(sizeof(T) == 8 && NN == 14)) {                          \
+    if constexpr (resident_built<T, NN>()) {                                \
         if (a.n == NN) return launch_pcg_resident_n<T, NN>(dev, a, s, err); \
     }
     GBDPCG_RESIDENT_N(GBDPCG_X)

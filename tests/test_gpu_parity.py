@@ -252,18 +252,20 @@ def test_ragged_convergence_in_one_batch(solver, orc, path):
 
 
 # DenseGeom::MAX_KNOTS = 8 waves x floor(64 / lanes per knot); fp32 with an even block size runs two rows per lane, everything else one
-RES_MAX = {np.float32: {2: 512, 4: 256, 6: 168, 8: 128, 10: 96, 12: 80, 3: 168, 5: 96, 7: 72, 9: 56, 11: 40, 13: 32},
+RES_MAX = {np.float32: {2: 512, 4: 256, 6: 168, 8: 128, 10: 96, 12: 80, 3: 168, 5: 96, 7: 72, 9: 56, 11: 40, 13: 32, 15: 32},
            np.float64: {2: 256, 4: 128, 6: 80, 8: 64, 10: 48, 12: 40, 3: 168, 5: 96, 7: 72, 9: 56, 11: 40, 13: 32}}
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("n", [2, 4, 6, 8, 10, 12, 3, 5, 7, 9, 11, 13])
+@pytest.mark.parametrize("n", [2, 4, 6, 8, 10, 12, 3, 5, 7, 9, 11, 13, 15])
 def test_register_resident_kernel_of_the_small_blocks(solver, orc, dtype, n):
     """pcg_resident_kernel is built for n in {2 (from 16 knots on), 3, ..., 13} as well as 14 (fp32 at even sizes: two rows per lane, else one): both matrices
     in the registers of one workgroup for the whole solve, several workgroups per compute unit.  Against the oracle at the
     longest horizon the block size allows, one knot beyond it (the streaming kernel takes over: same answers), one knot,
     batches larger than the grid (every workgroup walks several problems), with and without a preconditioner, from a warm
     start, and with r / p checked after a fixed number of iterations."""
+    if n == 15 and dtype == np.float64:
+        pytest.skip("fp64 at stateSize 15 is the cluster kernel's (180 matrix registers)")
     tol = F64_TOL if dtype == np.float64 else F32_TOL
     top = RES_MAX[dtype][n]
     for N, B, pinv in ((top, 3, True), (top + 1, 2, True), (1, 5, True), (top // 2 + 1, 3, False), (9, 1300, True)):
