@@ -63,7 +63,9 @@ constexpr int kClSc1 = 16;   // cache-policy bits of the raw buffer builtins on 
 //         the knot (the lane's 8 bytes of payload: two fp32 rows, one fp64 row, or one fp32 row), up to 16 lanes
 //   +384  the last own knot, for the right neighbour
 constexpr uint32_t kClLeftOff = 256, kClCtrlBytes = 256 + 256 * 16, kClSlotBytes = 640, kClFirstOff = 128, kClLastOff = 384;
-constexpr uint32_t kClMaxH = 4;
+// members of a cluster at most: the polling wave gives PPM lanes to every member's partials (fp32: 4, fp64: 8) and has 32 for them
+// (round 3: eight in fp32 -- 1024 converged solves of 14 x 300: 1,897 us streamed -> 997 us, one problem of 14 x 512: 85 -> 59 us)
+template <typename T> constexpr uint32_t cl_max_members() { return sizeof(T) == 4 ? 8u : 4u; }
 constexpr uint32_t kClEpochBits = 20, kClLaunchMod = 4095;   // tag = ((launch mod 4095) + 1) << 20 | epoch
 
 
@@ -708,7 +710,7 @@ void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
     X(double, 13, 1) X(double, 14, 1) X(double, 15, 1) X(double, 16, 1)
 
 // General storage, horizons beyond what ONE workgroup keeps in registers (pcg_resident.hip: 8 waves x floor(64 / (n / V)) knots
-// -- 72 at n = 14 in fp32) up to kClMaxH times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
+// -- 72 at n = 14 in fp32) up to eight (fp64: four) times that.  GBDPCG_NO_CLUSTER disables the path (tuning runs).
 template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
 {
     static const bool off = getenv("GBDPCG_NO_CLUSTER") != nullptr;
@@ -728,7 +730,7 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
     // (n = 2 below 16 knots stays with the streaming kernel, as in pcg_resident.hip: the reference's own example system lives there)
     if (N <= per_wg && (no_single || N < 2 || (n == 2 && N < 16))) return 0;
     const uint32_t H = (N + per_wg - 1) / per_wg;
-    return H <= kClMaxH ? H : 0;
+    return H <= cl_max_members<T>() ? H : 0;
 }
 
 // ... plus 16 bytes per CU behind the slots: start / end of every workgroup on the real-time clock (diagnostic build only)
@@ -741,7 +743,7 @@ size_t cluster_rescue_bytes(const DeviceInfo &dev)
     size_t bytes = 0;
 #define GBDPCG_X(TT, NN, VV)                                                                                      \
     {                                                                                                              \
-        const size_t e = rescue_vec_elems<TT>(NN, kClMaxH * DenseGeom<TT, NN, VV>::MAX_KNOTS) * sizeof(TT);       \
+        const size_t e = rescue_vec_elems<TT>(NN, cl_max_members<TT>() * DenseGeom<TT, NN, VV>::MAX_KNOTS) * sizeof(TT); \
         bytes = e > bytes ? e : bytes;                                                                             \
     }
     GBDPCG_CLUSTER_SHAPES(GBDPCG_X)

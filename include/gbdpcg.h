@@ -106,9 +106,9 @@ gbdpcg_status gbdpcg_set_path(gbdpcg_handle_t h, gbdpcg_path path);
 gbdpcg_path gbdpcg_choose_path(gbdpcg_handle_t h, uint32_t elem_size, uint32_t n, uint32_t N,
                                uint32_t batch);
 /* Compute units a GENERAL-storage problem of this shape is spread over inside the fused path (pcg_cluster.hip: both
- * matrices register-resident for the whole solve, 1-4 workgroups per problem exchanging inner-product partials and
- * boundary knots twice per iteration): built for stateSize 2 ... 16 and 18 in fp32, 2 ... 16 in fp64, horizons up to four
- * times what one workgroup holds (stateSize 14, fp32: 72 < knotPoints <= 288).  0 = the shape has no such form: the
+ * matrices register-resident for the whole solve, 1-8 workgroups per problem (fp64: 1-4) exchanging inner-product partials and
+ * boundary knots twice per iteration): built for stateSize 2 ... 16 and 18 in fp32, 2 ... 16 in fp64, horizons up to eight
+ * (fp64: four) times what one workgroup holds (stateSize 14, fp32: 72 < knotPoints <= 576).  0 = the shape has no such form: the
  * single-workgroup resident kernel has it (short horizons of stateSize 2 ... 14), or general storage is streamed every
  * iteration (larger blocks, longer horizons). */
 uint32_t gbdpcg_cluster_members(uint32_t elem_size, uint32_t n, uint32_t N);

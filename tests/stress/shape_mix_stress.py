@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Random shapes on ONE handle, back to back: every on-chip kernel family (single-workgroup resident, clusters of one to four
-members in both precisions, persistent, persistent in slices) and the streaming ones take turns, in random symmetric modes, and
+"""Random shapes on ONE handle, back to back: every on-chip kernel family (single-workgroup resident, clusters of one to eight
+members (fp64: four), persistent, persistent in slices) and the streaming ones take turns, in random symmetric modes, and
 every problem is compared with the CPU oracle (the checker; this file lives under tests/ for that reason).  The cluster kernels
 share one hand-off workspace across shapes: a stale granule of one shape must never satisfy a poll of another.
      python tests/stress/shape_mix_stress.py [cases=150] [seed=1]"""
@@ -29,7 +29,7 @@ for c in range(cases):
         N, B = int(rng.integers(8, 140)), int(rng.choice([1, 2, 3, 5, 8]))
     else:
         per_wg = 8 * (64 // (n if (f64 or n % 2) else n // 2))
-        N = int(rng.integers(2, min(4 * per_wg, 400) + 1))
+        N = int(rng.integers(2, min((4 if f64 else 8) * per_wg, 600) + 1))
         B = int(rng.choice([1, 2, 7, 33, 130, 300]))
     dt = np.float64 if f64 else np.float32
     es = 8 if f64 else 4

@@ -79,11 +79,11 @@ def test_cluster_shapes(solver):
     assert solver.cluster_members(4, 14, 128) == 2 and solver.cluster_members(4, 14, 144) == 2
     assert solver.cluster_members(4, 14, 145) == 3 and solver.cluster_members(4, 14, 288) == 4
     assert solver.cluster_members(4, 14, 72) == 0      # one workgroup holds it (pcg_resident.hip)
-    assert solver.cluster_members(4, 14, 289) == 0
+    assert solver.cluster_members(4, 14, 289) == 5 and solver.cluster_members(4, 14, 576) == 8 and solver.cluster_members(4, 14, 577) == 0
     assert solver.cluster_members(4, 36, 128) == 0
     # stateSize 12 (round 3): 80 knots per workgroup
     assert solver.cluster_members(4, 12, 80) == 0 and solver.cluster_members(4, 12, 81) == 2 and solver.cluster_members(4, 12, 128) == 2
-    assert solver.cluster_members(4, 12, 161) == 3 and solver.cluster_members(4, 12, 320) == 4 and solver.cluster_members(4, 12, 321) == 0
+    assert solver.cluster_members(4, 12, 161) == 3 and solver.cluster_members(4, 12, 320) == 4 and solver.cluster_members(4, 12, 321) == 5 and solver.cluster_members(4, 12, 641) == 0
     # one row per lane: stateSize 13 in fp32 and the BASELINE block size in fp64 (32 knots per workgroup)
     assert solver.cluster_members(4, 13, 32) == 0 and solver.cluster_members(4, 13, 33) == 2 and solver.cluster_members(4, 13, 128) == 4
     assert solver.cluster_members(8, 14, 32) == 1 and solver.cluster_members(8, 14, 64) == 2 and solver.cluster_members(8, 14, 128) == 4
@@ -96,18 +96,19 @@ def test_cluster_shapes(solver):
     assert solver.cluster_members(8, 12, 40) == 0 and solver.cluster_members(8, 12, 128) == 4 and solver.cluster_members(8, 12, 161) == 0
     assert solver.cluster_members(8, 10, 48) == 0 and solver.cluster_members(8, 10, 128) == 3 and solver.cluster_members(8, 8, 128) == 2
     assert solver.cluster_members(4, 9, 56) == 0 and solver.cluster_members(4, 9, 128) == 3 and solver.cluster_members(4, 11, 128) == 4
-    assert solver.cluster_members(4, 15, 32) == 0 and solver.cluster_members(4, 15, 128) == 4 and solver.cluster_members(4, 15, 129) == 0
+    assert solver.cluster_members(4, 15, 32) == 0 and solver.cluster_members(4, 15, 128) == 4 and solver.cluster_members(4, 15, 129) == 5 and solver.cluster_members(4, 15, 257) == 0
     # stateSize 18: 9 lanes per knot, 56 knots per workgroup, the D and R blocks of Pinv in LDS
     assert solver.cluster_members(4, 18, 56) == 1 and solver.cluster_members(4, 18, 128) == 3 and solver.cluster_members(4, 18, 224) == 4
-    assert solver.cluster_members(4, 18, 225) == 0 and solver.cluster_members(8, 18, 128) == 0 and solver.cluster_members(4, 20, 128) == 0
+    assert solver.cluster_members(4, 18, 225) == 5 and solver.cluster_members(4, 18, 449) == 0 and solver.cluster_members(8, 18, 128) == 0 and solver.cluster_members(4, 20, 128) == 0
     # the small blocks beyond pcg_resident.hip's horizons (512 / 256 / 168 knots in fp32); the reference's example system (2 x 3) streams
     assert solver.cluster_members(4, 2, 512) == 0 and solver.cluster_members(4, 2, 513) == 2 and solver.cluster_members(4, 2, 3) == 0
-    assert solver.cluster_members(4, 4, 1024) == 4 and solver.cluster_members(4, 4, 1025) == 0 and solver.cluster_members(8, 6, 81) == 2
+    assert solver.cluster_members(4, 4, 1024) == 4 and solver.cluster_members(4, 4, 1025) == 5 and solver.cluster_members(8, 6, 81) == 2
     # fp64 at stateSize 16: 16 lanes per knot, 32 knots per workgroup, the D and R blocks of Pinv in LDS
     assert solver.cluster_members(8, 16, 32) == 1 and solver.cluster_members(8, 16, 128) == 4 and solver.cluster_members(8, 16, 129) == 0
 
 
-@pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (73, 2), (100, 9), (144, 3), (145, 2), (200, 4), (216, 1), (217, 2), (288, 3)])
+@pytest.mark.parametrize("N,B", [(128, 5), (127, 3), (73, 2), (100, 9), (144, 3), (145, 2), (200, 4), (216, 1), (217, 2), (288, 3),
+                                 (289, 2), (300, 40), (433, 2), (505, 1), (576, 3)])   # five to eight members (fp32 only)
 def test_cluster_vs_oracle(solver, orc, N, B):
     """Two, three and four workgroups per problem, even and ragged splits, more and fewer problems than one round."""
     n = 14
@@ -120,7 +121,8 @@ def test_cluster_vs_oracle(solver, orc, N, B):
 @pytest.mark.parametrize("n,N,B", [(12, 128, 5), (12, 81, 3), (12, 100, 140), (12, 160, 2), (12, 161, 3), (12, 240, 70), (12, 320, 2),
                                    (12, 319, 1), (8, 129, 3), (8, 256, 70), (8, 300, 2), (8, 512, 1), (10, 97, 2), (10, 128, 140), (10, 200, 3),
                                    (10, 384, 2), (16, 65, 2), (16, 128, 140), (16, 129, 3), (16, 200, 70), (16, 256, 2),
-                                   (18, 57, 2), (18, 112, 3), (18, 113, 2), (18, 128, 140), (18, 168, 70), (18, 224, 2)])
+                                   (18, 57, 2), (18, 112, 3), (18, 113, 2), (18, 128, 140), (18, 168, 70), (18, 224, 2),
+                                   (12, 400, 3), (12, 640, 1), (8, 1000, 2), (10, 700, 2), (16, 300, 40), (16, 512, 1), (18, 300, 2), (18, 448, 1)])
 def test_cluster_other_state_sizes(solver, orc, n, N, B):
     """The same kernel at stateSize 8, 10, 12, 16 and 18 (n / 2 lanes per knot, 128 / 96 / 80 / 64 / 56 knots per workgroup; at 16 the R
     block of Pinv stays in LDS, at 18 its D block as well): two, three and four workgroups per problem, ragged splits, more problems
@@ -158,7 +160,8 @@ def test_cluster_other_state_sizes(solver, orc, n, N, B):
                                          (2, np.float32, 513, 3), (2, np.float32, 2048, 2), (2, np.float32, 700, 70), (4, np.float32, 257, 3),
                                          (4, np.float32, 600, 70), (4, np.float32, 1024, 1), (6, np.float32, 169, 70), (6, np.float32, 672, 2),
                                          (2, np.float64, 300, 70), (2, np.float64, 1024, 2), (4, np.float64, 129, 3), (4, np.float64, 512, 5),
-                                         (6, np.float64, 81, 70), (6, np.float64, 320, 2)])
+                                         (6, np.float64, 81, 70), (6, np.float64, 320, 2), (13, np.float32, 200, 3), (13, np.float32, 256, 1), (9, np.float32, 400, 40),
+                                         (7, np.float32, 500, 70), (3, np.float32, 1300, 2), (15, np.float32, 250, 2), (11, np.float32, 300, 3)])
 def test_cluster_one_row_per_lane(solver, orc, n, dtype, N, B):
     """One row per lane: the BASELINE block size in fp64 (14 lanes per knot, 32 knots per workgroup, the
     hand-off words carry both halves of an fp64 value under their own tags) and stateSize 13 in fp32 (13 lanes per knot, direct

@@ -262,13 +262,14 @@ def test_small_batches_of_large_problems_go_persistent_in_slices(solver, orc, n,
 def test_auto_takes_the_persistent_path_for_one_long_horizon_problem(solver):
     # block sizes beyond the on-chip kernels: one problem goes persistent instead of through 2 max_iter + 4 launches of the split path
     assert solver.choose_path(4, 24, 128, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 20, 64, 1) == binding.PATH_PERSISTENT
-    assert solver.choose_path(4, 16, 300, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 16, 128, 1) == binding.PATH_FUSED
+    assert solver.choose_path(4, 16, 600, 1) == binding.PATH_PERSISTENT and solver.choose_path(4, 16, 128, 1) == binding.PATH_FUSED
     assert solver.choose_path(4, 22, 128, 1) == binding.PATH_PERSISTENT and solver.choose_path(8, 32, 64, 1) == binding.PATH_PERSISTENT
     assert solver.choose_path(4, 38, 128, 1) == binding.PATH_SPLIT           # no persistent kernel of that size
     assert solver.choose_path(8, 14, 256, 1) == binding.PATH_PERSISTENT      # 2.4 MB per iteration through one CU otherwise
     # fp32: four CUs keep it resident on the cluster path (3.7 us per iteration against 4.7 here, tools/ab_cluster.py 256 1)
     assert solver.choose_path(4, 14, 256, 1) == binding.PATH_FUSED and solver.cluster_members(4, 14, 256) == 4
-    assert solver.choose_path(4, 14, 300, 1) == binding.PATH_PERSISTENT      # beyond four CUs' worth of knots
+    assert solver.choose_path(4, 14, 300, 1) == binding.PATH_FUSED and solver.cluster_members(4, 14, 300) == 5   # up to eight CUs in fp32
+    assert solver.choose_path(4, 14, 600, 1) == binding.PATH_PERSISTENT      # beyond eight CUs' worth of knots
     assert solver.choose_path(4, 14, 128, 1) == binding.PATH_FUSED           # symmetric halves resident on one CU (default mode 2)
     assert solver.choose_path(4, 14, 64, 1) == binding.PATH_FUSED            # register-resident
     assert solver.choose_path(4, 14, 256, 64) == binding.PATH_FUSED or solver.choose_path(4, 14, 256, 64) == binding.PATH_SPLIT
