@@ -70,7 +70,7 @@ if [ -f $ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_rsstamps.so ]; then
   GBDPCG_LIB=$ROOT/gbd-pcg_amd/csrc/variants/libgbdpcg_rsstamps.so python3 $ROOT/gbd-pcg_amd/tools/rs_stamps.py > $OUT/resident_stamps.txt 2>/dev/null || true
 fi
 echo "[14] converged / fixed-count solves by shape on the default path (solve_shapes.py)"
-python3 $ROOT/gbd-pcg_amd/tools/solve_shapes.py 14,128,1024,f32 12,128,1024,f32 16,128,1024,f32 10,128,1024,f32 8,256,1024,f32 13,128,1024,f32 3,128,1024,f32 5,128,1024,f32 7,128,1024,f32 7,64,1024,f32 9,128,1024,f32 11,128,1024,f32 15,128,1024,f32 18,128,1024,f32 20,128,1024,f32 14,128,1024,f64 13,128,1024,f64 7,128,1024,f64 16,128,1024,f64 12,128,1024,f64 10,128,1024,f64 8,128,1024,f64 14,256,64,f32 14,64,1,f32 36,256,1,f64 > $OUT/solve_shapes.jsonl 2>/dev/null || true
+python3 $ROOT/gbd-pcg_amd/tools/solve_shapes.py 14,128,1024,f32 12,128,1024,f32 16,128,1024,f32 10,128,1024,f32 8,256,1024,f32 13,128,1024,f32 3,128,1024,f32 5,128,1024,f32 7,128,1024,f32 7,64,1024,f32 9,128,1024,f32 11,128,1024,f32 15,128,1024,f32 18,128,1024,f32 20,128,1024,f32 14,128,1024,f64 13,128,1024,f64 7,128,1024,f64 16,128,1024,f64 12,128,1024,f64 10,128,1024,f64 8,128,1024,f64 14,256,64,f32 14,300,1024,f32 14,512,256,f32 8,600,512,f32 14,64,1,f32 36,256,1,f64 > $OUT/solve_shapes.jsonl 2>/dev/null || true
 echo "[14b] one problem by shape (which path takes it), stair formation and SpMV by block size"
 python3 $ROOT/gbd-pcg_amd/tools/solve_shapes.py 14,64,1,f32 14,128,1,f32 14,300,1,f32 16,300,1,f32 18,128,1,f32 20,64,1,f32 24,128,1,f32 36,256,1,f32 13,32,1,f32 14,32,1,f64 14,256,1,f64 24,256,1,f64 36,256,1,f64 36,256,2,f64 36,256,4,f64 36,256,8,f64 24,128,8,f32 20,64,12,f32 14,128,16,f32 14,128,128,f32 > $OUT/single_problem.jsonl 2>/dev/null || true
 python3 $ROOT/gbd-pcg_amd/tools/pinv_shapes.py > $OUT/pinv_shapes.txt 2>/dev/null || true
