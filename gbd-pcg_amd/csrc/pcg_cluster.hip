@@ -126,7 +126,10 @@ template <typename T, int NCT, int V, bool STAGED> struct ClusterTailBytes {
 template <typename T, int NCT> struct ClusterLight {
     static constexpr bool value = (sizeof(T) == 4 && (NCT <= 7 || NCT == 9 || NCT == 11 || NCT == 13 || NCT == 15)) || (sizeof(T) == 8 && NCT <= 5);
 };
-template <typename T, int NCT, int V, bool STAGED>
+// ONE: a cluster of one workgroup (launch_pcg_cluster: only where the shape has such launches) -- nobody to hand anything to, the wave
+// partials meet in LDS, in the same words and the same sum as in memory.  A compile-time switch: as a run-time test inside the
+// hand-off it cost the clusters of two to four members 4 %.
+template <typename T, int NCT, int V, bool STAGED, bool ONE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(ClusterLight<T, NCT>::value ? 4 : 2)))
 void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
                                                           uint32_t clusters, uint32_t spin_limit, uint32_t drop_block, bool no_plain)
@@ -147,6 +150,7 @@ void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
     __shared__ T bc[4];           // [0] alpha / eta' of the phase just gathered, [1] beta
     __shared__ uint32_t bci[4];   // [0] 0 go on, 1 converged, 2 hand-off timed out; [2], [3] the rescue's bookkeeping
     __shared__ T rescue_red[2 * Dg::WAVES];
+    __shared__ cl_u32x4 lpart[ONE ? Dg::WAVES : 1];   // ONE: the wave partials of a hand-off, laid out like the slot in memory
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];   // STAGED: dense_stage_lds_bytes (bt_dense.hpp)
     // The last PTAIL columns of this lane's block-row of Pinv (its V rows each) live in LDS instead of registers (dense_mv, TAIL):
     // at n = 16 the whole R block of Pinv -- 2 x 96 matrix registers per lane do not fit next to the working set, 96 + 64 do;
@@ -230,7 +234,12 @@ void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
                       o_first = (int)(par_off + my_slot + kClFirstOff + lo * 16),                                    \
                       o_last = (int)(par_off + my_slot + kClLastOff + (lo - lb * LPB) * 16);                         \
             const bool p_first = wave == 0 && has_left && lo < LPB, p_last = wave == wl && has_right && lo - lb * LPB < LPB; \
-            if (same_xcd) {   /* plain: the line stays in this XCD's L2, where every member of the cluster polls */   \
+            if constexpr (ONE) {                                                                                     \
+                if (lo == 0) {                                                                                       \
+                    if constexpr (sizeof(T) == 4) reinterpret_cast<cl_u32x2 *>(lpart)[wave] = x2;                    \
+                    else lpart[wave] = x4;                                                                           \
+                }                                                                                                    \
+            } else if (same_xcd) {   /* plain: the line stays in this XCD's L2, where every member of the cluster polls */   \
                 if (lo == 0) {                                                                                       \
                     if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b64(x2, region, o_part, 0, 0);   \
                     else __builtin_amdgcn_raw_buffer_store_b128(x4, region, o_part, 0, 0);                           \
@@ -246,6 +255,7 @@ void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
                 if (p_last) __builtin_amdgcn_raw_buffer_store_b128(bx, region, o_last, 0, kClSc1);                   \
             }                                                                                                        \
         }                                                                                                            \
+        if constexpr (ONE) wg_barrier();                                                                             \
         if (wave == POLL) {                                                                                          \
             uint32_t poll_off = 0;                                                                                   \
             bool have = true;                                                                                        \
@@ -268,6 +278,10 @@ void pcg_cluster_kernel(PcgArgs<T> a, unsigned char *ws, uint32_t H, uint32_t C,
             }                                                                                                        \
             cl_u32x4 got = {0u, 0u, 0u, 0u};                                                                         \
             OK = true;                                                                                               \
+            if constexpr (ONE) {                                                                                     \
+                got = lpart[lo < PPM ? lo : 0u];                                                                     \
+                OK = blk != drop_block;                                                                              \
+            } else                                                                                                   \
             for (uint32_t spins = 0;; ++spins) {                                                                     \
                 asm volatile("" ::: "memory");   /* the poll is re-issued on every pass */                           \
                 if (!have) {   /* only the lanes that still miss their piece load again */                           \
@@ -722,9 +736,7 @@ template <typename T> uint32_t cluster_members(uint32_t n, uint32_t N)
 #undef GBDPCG_X
     if (per_wg == 0) return 0;                  // not built for the block size
     // one workgroup holds the whole problem: pcg_resident.hip where it is built for the block size (its reductions stay in LDS); a
-    // "cluster" of one elsewhere (odd block sizes, 16 and 18, fp64 from 14 on) -- the kernel as it is, its one member polling its own
-    // partials (through LDS instead they would come 8 % sooner -- 114 vs 124 us per 1024 converged solves at 13 x 32 -- but the test
-    // for it inside the hand-off cost the clusters of two to four members 4 %: measured, taken out again)
+    // "cluster" of one elsewhere (16 and 18, fp64 from 14 on) -- the kernel's ONE instantiation, whose wave partials meet in LDS
     if (N <= per_wg && resident_shape<T>(n, N)) return 0;
     static const bool no_single = getenv("GBDPCG_NO_CLUSTER_OF_ONE") != nullptr;   // tuning runs
     // (n = 2 below 16 knots stays with the streaming kernel, as in pcg_resident.hip: the reference's own example system lives there)
@@ -805,6 +817,16 @@ bool launch_pcg_cluster(const DeviceInfo &dev, const PcgArgs<T> &a, hipStream_t 
                 if (staged) {                                                                                            \
                     kern = pcg_cluster_kernel<T, NN, VV, true>;                                                          \
                     if (dense_stage_lds_bytes<TT, NN, VV>() > lds) lds = dense_stage_lds_bytes<TT, NN, VV>();            \
+                }                                                                                                        \
+            }                                                                                                            \
+            /* a cluster of one: the instantiation whose partials meet in LDS, where the block size has such launches   \
+               (no single-workgroup kernel in pcg_resident.hip: fp32 16 and 18, fp64 14, 15, 16) */                      \
+            if constexpr (!ClusterLight<TT, NN>::value && ((sizeof(TT) == 4 && NN >= 16) || (sizeof(TT) == 8 && NN >= 14))) { \
+                if (H == 1) {                                                                                            \
+                    kern = pcg_cluster_kernel<T, NN, VV, false, true>;                                                   \
+                    if constexpr (can_stage) {                                                                           \
+                        if (staged) kern = pcg_cluster_kernel<T, NN, VV, true, true>;                                    \
+                    }                                                                                                    \
                 }                                                                                                        \
             }                                                                                                            \
             /* on every launch, like the other launchers: HIP keeps the attribute per device */                          \
