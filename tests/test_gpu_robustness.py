@@ -214,6 +214,39 @@ def test_solve_inside_a_caller_owned_capture(solver, orc):
         assert np.linalg.norm(lam_h[b] - ob["lambda_"][b]) / np.linalg.norm(ob["lambda_"][b]) < 1e-6
 
 
+def test_sliced_persistent_solve_inside_a_caller_owned_capture(orc):
+    """The same for a small batch of large problems, which AUTO cuts into persistent launches in a row (api.hip, persist_slices):
+    gbdpcg_reserve prepares the hand-off words of the slices (and the split path's workspace -- which of the two a solve takes
+    depends on its max_iter), so both captures below are legal; a fresh handle, so that nothing is there by accident."""
+    n, N, B = 24, 100, 7
+    s = binding.Solver(0)
+    try:
+        d = synth.gen_numpy(n, N, seed=405, batch=B, dtype=np.float32)
+        S, P, g = dev(d["S"]), dev(d["Pinv"]), dev(d["gamma"])
+        iters = torch.zeros(B, dtype=torch.int32, device="cuda")
+        flags = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        s.reserve(4, n, N, B)
+        torch.cuda.synchronize()
+        for max_iter in (60, 8):   # 60: persistent launches in a row; 8: the split graph is the shorter one
+            lam = torch.zeros_like(g)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                s.solve(n, N, B, S, P, g, lam, tol=1e-6, max_iter=max_iter, iters=iters, max_iter_exit=flags)
+            for _ in range(2):
+                lam.zero_()
+                graph.replay()
+            torch.cuda.synchronize()
+            ob = orc.pcg_batch(n, N, B, d["S"], d["Pinv"], d["gamma"], tol=1e-6, max_iter=max_iter, nthreads=4)
+            assert np.array_equal(iters.cpu().numpy().astype(np.int64), ob["iters"].astype(np.int64)), max_iter
+            assert np.array_equal(flags.cpu().numpy().astype(bool), ob["max_iter_exit"].astype(bool))
+            lam_h = lam.cpu().numpy().reshape(B, -1)
+            for b in range(B):
+                assert np.linalg.norm(lam_h[b] - ob["lambda_"][b]) / np.linalg.norm(ob["lambda_"][b]) < 2e-6, (max_iter, b)
+            del graph
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("shape", [(14, 40, 3, 400, np.float32), (36, 256, 1, 4, np.float64)])
 def test_graph_survives_growth_of_the_handle_buffers(orc, shape):
     """A graph holds the handle's scratch (the verdict bytes of the device symmetry check; the split path's
